@@ -1,0 +1,125 @@
+/* cs_arith.h -- saturating int32 bound arithmetic and interval helpers.
+ *
+ * One source for host C (gcc), host C++ and gfx950 device code: every function
+ * is `static inline` and carries CS_HD, which expands to `__host__ __device__`
+ * under hipcc and to nothing under a plain C compiler.
+ *
+ * Semantics follow the reference's scalar layer (reference src/arith.c:27-85)
+ * and the interval predicates of reference src/csolve.h:43-70:
+ *   - CS_DOM_MIN / CS_DOM_MAX are absorbing -inf / +inf sentinels,
+ *   - in cs_add -inf wins over +inf,
+ *   - in cs_mul a sentinel times zero keeps the sentinel's sign rule
+ *     (0 is treated as "not negative"),
+ *   - everything else clamps to the int32 range by sign.
+ * The code is a restatement through int64 clamping, not a transcription.
+ */
+#ifndef CS_ARITH_H
+#define CS_ARITH_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define CS_HD __host__ __device__
+#else
+#define CS_HD
+#endif
+
+#define CS_DOM_MIN INT32_MIN
+#define CS_DOM_MAX INT32_MAX
+
+/* closed interval [lo,hi]; layout == reference `struct val_t` (csolve.h:43-46) */
+typedef struct cs_val {
+  int32_t lo;
+  int32_t hi;
+} cs_val;
+
+CS_HD static inline int32_t cs_clamp64(int64_t x) {
+  return x > (int64_t)CS_DOM_MAX ? CS_DOM_MAX : (x < (int64_t)CS_DOM_MIN ? CS_DOM_MIN : (int32_t)x);
+}
+
+/* reference arith.c:27-35 */
+CS_HD static inline int32_t cs_neg(int32_t a) {
+  return a == CS_DOM_MIN ? CS_DOM_MAX : (a == CS_DOM_MAX ? CS_DOM_MIN : -a);
+}
+
+/* reference arith.c:38-51 */
+CS_HD static inline int32_t cs_add(int32_t a, int32_t b) {
+  if (a == CS_DOM_MIN || b == CS_DOM_MIN) return CS_DOM_MIN;
+  if (a == CS_DOM_MAX || b == CS_DOM_MAX) return CS_DOM_MAX;
+  return cs_clamp64((int64_t)a + (int64_t)b);
+}
+
+/* reference arith.c:54-75 */
+CS_HD static inline int32_t cs_mul(int32_t a, int32_t b) {
+  if (a == CS_DOM_MIN) return b < 0 ? CS_DOM_MAX : CS_DOM_MIN;
+  if (b == CS_DOM_MIN) return a < 0 ? CS_DOM_MAX : CS_DOM_MIN;
+  if (a == CS_DOM_MAX) return b < 0 ? CS_DOM_MIN : CS_DOM_MAX;
+  if (b == CS_DOM_MAX) return a < 0 ? CS_DOM_MIN : CS_DOM_MAX;
+  return cs_clamp64((int64_t)a * (int64_t)b);
+}
+
+/* reference arith.c:78-85 */
+CS_HD static inline int32_t cs_min(int32_t a, int32_t b) { return a < b ? a : b; }
+CS_HD static inline int32_t cs_max(int32_t a, int32_t b) { return a > b ? a : b; }
+
+CS_HD static inline cs_val cs_interval(int32_t lo, int32_t hi) {
+  cs_val v;
+  v.lo = lo;
+  v.hi = hi;
+  return v;
+}
+CS_HD static inline cs_val cs_value(int32_t x) { return cs_interval(x, x); }
+
+/* reference csolve.h:57-67 */
+CS_HD static inline int cs_is_value(cs_val v) { return v.lo == v.hi; }
+CS_HD static inline int cs_is_true(cs_val v) { return v.lo > 0 || v.hi < 0; }
+CS_HD static inline int cs_is_false(cs_val v) { return v.lo == 0 && v.hi == 0; }
+
+/* any bound sitting on a sentinel: comparisons give up (eval.c:47-50, 81-84) */
+CS_HD static inline int cs_unbounded2(cs_val a, cs_val b) {
+  return a.lo == CS_DOM_MIN || a.hi == CS_DOM_MAX || b.lo == CS_DOM_MIN || b.hi == CS_DOM_MAX;
+}
+CS_HD static inline int cs_is_sentinel(int32_t x) { return x == CS_DOM_MIN || x == CS_DOM_MAX; }
+
+/* three-valued truth as an interval */
+CS_HD static inline cs_val cs_tv(int must_true, int must_false) {
+  return must_true ? cs_value(1) : (must_false ? cs_value(0) : cs_interval(0, 1));
+}
+
+/* ---- interval evaluation of one operator from child intervals ---- */
+
+/* reference eval.c:32-63 */
+CS_HD static inline cs_val cs_ev_eq(cs_val a, cs_val b) {
+  if (cs_unbounded2(a, b)) return cs_interval(0, 1);
+  return cs_tv(a.lo == a.hi && a.lo == b.lo && a.hi == b.hi, a.hi < b.lo || a.lo > b.hi);
+}
+/* reference eval.c:66-97 */
+CS_HD static inline cs_val cs_ev_lt(cs_val a, cs_val b) {
+  if (cs_unbounded2(a, b)) return cs_interval(0, 1);
+  return cs_tv(a.hi < b.lo, a.lo >= b.hi);
+}
+/* reference eval.c:100-114 */
+CS_HD static inline cs_val cs_ev_neg(cs_val a) { return cs_interval(cs_neg(a.hi), cs_neg(a.lo)); }
+/* reference eval.c:117-135 */
+CS_HD static inline cs_val cs_ev_add(cs_val a, cs_val b) {
+  return cs_interval(cs_add(a.lo, b.lo), cs_add(a.hi, b.hi));
+}
+/* reference eval.c:138-160 */
+CS_HD static inline cs_val cs_ev_mul(cs_val a, cs_val b) {
+  int32_t p0 = cs_mul(a.lo, b.lo), p1 = cs_mul(a.lo, b.hi);
+  int32_t p2 = cs_mul(a.hi, b.lo), p3 = cs_mul(a.hi, b.hi);
+  return cs_interval(cs_min(cs_min(p0, p1), cs_min(p2, p3)), cs_max(cs_max(p0, p1), cs_max(p2, p3)));
+}
+/* reference eval.c:163-180 */
+CS_HD static inline cs_val cs_ev_not(cs_val a) { return cs_tv(cs_is_false(a), cs_is_true(a)); }
+/* reference eval.c:183-205 (short-circuit order does not change the value) */
+CS_HD static inline cs_val cs_ev_and(cs_val a, cs_val b) {
+  return cs_tv(cs_is_true(a) && cs_is_true(b), cs_is_false(a) || cs_is_false(b));
+}
+/* reference eval.c:208-230 */
+CS_HD static inline cs_val cs_ev_or(cs_val a, cs_val b) {
+  return cs_tv(cs_is_true(a) || cs_is_true(b), cs_is_false(a) && cs_is_false(b));
+}
+
+#endif /* CS_ARITH_H */

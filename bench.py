@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py -- constraint propagations/s and nodes/s of the HIP propagation fixpoint.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1]): queens-64 (text identical to what the reference's
+scripts/gen_queens.sh writes), propagation-only.  The node instances are produced by
+seeded random assignment walks: from the root fixpoint pick a random open
+variable and a random value of its interval, propagate, continue from the result; a walk
+restarts at the first inconsistent node or when every variable is assigned.  Every step
+of every walk is one instance (state-before, variable, value) -> (state-after | FAIL).
+The instance set is generated once with the device path (untimed) and then stays resident
+in HBM.  One "step" = one launch of the batched fixpoint kernel over the whole instance
+set.  With N ranks every rank owns its own instance set of the same size (weak scaling);
+nodes are independent, so the data path has no collective.
+
+Prints ONE JSON line (rank 0): value = narrowing events ("propagations", the reference's
+PROPS counter, propagate.c:77-78) per second over all ranks; `roofline` for the fixpoint
+kernel from HIP-event timing; `cpu_baseline` = the CPU oracle (a bit-checked restatement
+of the reference propagator) timed on one host core on a bounded sample of the same
+instances, which also re-checks the device results on that sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from csolve_amd import problems  # noqa: E402
+from csolve_amd.solver import solve_root  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def make_instances(model, count, seed, walks=8192):
+    """Seeded random walks on the device path.  -> states_in [count,n,2] (cuda), nodes [count,4] (cuda)"""
+    n = model.n_vars
+    root = model.domains()
+    rng = np.random.default_rng(seed)
+    walks = min(walks, count)
+    cur = np.repeat(root[None], walks, 0)
+    states, nodes = [], []
+    have = 0
+    while have < count:
+        open_mask = cur[:, :, 0] < cur[:, :, 1]
+        done = ~open_mask.any(1)
+        cur[done] = root
+        open_mask[done] = root[:, 0] < root[:, 1]
+        # random open variable per walk, random value of its interval
+        keys = rng.random(open_mask.shape)
+        keys[~open_mask] = -1.0
+        var = keys.argmax(1)
+        lo = cur[np.arange(walks), var, 0]
+        hi = cur[np.arange(walks), var, 1]
+        val = lo + (rng.random(walks) * (hi - lo + 1)).astype(np.int64).clip(0, hi - lo)
+        nd = np.stack([var, val, val, np.arange(walks)], 1).astype(np.int32)
+        d_cur = torch.from_numpy(cur).cuda()
+        out, res = model.propagate(d_cur, torch.from_numpy(nd).cuda())
+        torch.cuda.synchronize()
+        take = min(walks, count - have)
+        states.append(d_cur[:take].clone())
+        nd_take = nd[:take].copy()
+        nd_take[:, 3] = np.arange(have, have + take)
+        nodes.append(torch.from_numpy(nd_take).cuda())
+        have += take
+        ok = (res[:, 0] >= 0).cpu().numpy()
+        nxt = out.cpu().numpy()
+        nxt[~ok] = root
+        cur = nxt
+    return torch.cat(states).contiguous(), torch.cat(nodes).contiguous()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--queens", type=int, default=64)
+    ap.add_argument("--instances", type=int, default=1 << 18, help="node instances per GPU")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    n_q = args.queens
+    text = problems.queens(n_q)
+    model = solve_root(text)
+    n = model.n_vars
+    info = model.device_info()
+
+    states_in, nodes = make_instances(model, args.instances, seed=12345 + rank)
+    B = nodes.shape[0]
+    states_out = torch.empty((B, n, 2), dtype=torch.int32, device="cuda")
+    results = torch.empty((B, 4), dtype=torch.int32, device="cuda")
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        model.propagate(states_in, nodes, states_out, results)
+    barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        model.propagate(states_in, nodes, states_out, results)
+        ev[k][1].record()
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+
+    res_h = results.cpu().numpy().astype(np.int64)
+    totals = torch.tensor([res_h[:, 1].sum(), res_h[:, 2].sum(), B, int((res_h[:, 0] < 0).sum())],
+                          dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(totals, op=dist.ReduceOp.SUM)
+    props_all, revs_all, nodes_all, fails_all = [float(x) for x in totals.tolist()]
+
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    props_r, revs_r = int(res_h[:, 1].sum()), int(res_h[:, 2].sum())
+    # 32 B per clause revision + 8 B per narrowing + 16 B * n per node instance
+    alg_bytes = 32 * revs_r + 8 * props_r + 16 * n * B
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    stream_bytes = (16 * n + 16 + 16) * B  # what must cross HBM: state in + out, node record, result
+    out = {
+        "metric": "constraint propagations/sec + nodes/sec, queens-N, 1/2/4/8 MI355X",
+        "value": props_all * args.steps / elapsed,
+        "unit": "propagations/s",
+        "nodes_per_s": nodes_all * args.steps / elapsed,
+        "revisions_per_s": revs_all * args.steps / elapsed,
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "int32",
+        "data": "synthetic",
+        "config": {"workload": f"queens-{n_q} propagation-only fixpoint (BASELINE configs[1]), seeded random-walk "
+                               f"node instances resident in HBM",
+                   "instances_per_gpu": B, "variables": n, "clauses": info["ne_clauses"] + info["tree_clauses"],
+                   "inconsistent_fraction": fails_all / nodes_all,
+                   "props_per_node": props_all / nodes_all, "revisions_per_node": revs_all / nodes_all},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "cs_propagate_events<false>", "kernel_ms": kernel_ms,
+                     "algorithmic_bytes_per_launch": alg_bytes,
+                     "hbm_stream_bytes_per_launch": stream_bytes,
+                     "hbm_stream_frac": stream_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu:
+        from oracle.cs_oracle import Model as OModel, Oracle
+        omodel = OModel.parse(text)
+        omodel.set_domains(model.domains())
+        omodel.index()
+        orc = Oracle(omodel)
+        si = states_in.cpu().numpy()
+        nd = nodes.cpu().numpy()
+        so = states_out.cpu().numpy()
+        chunk, done, binds, spent = 2048, 0, 0, 0.0
+        while done < B and spent < args.cpu_seconds:
+            sel = slice(done, min(B, done + chunk))
+            nd_c = nd[sel].copy()
+            nd_c[:, 3] -= done
+            c0 = time.perf_counter()
+            st, exp, b = orc.instances_nodes(si[sel], nd_c)
+            spent += time.perf_counter() - c0
+            binds += b
+            # the oracle as checker: verdicts, fixpoints and PROPS of the device results
+            fail = st < 0
+            assert (fail == (res_h[sel, 0] < 0)).all(), "device verdicts differ from the oracle"
+            assert (so[sel][~fail] == exp[~fail]).all(), "device fixpoints differ from the oracle"
+            assert (res_h[sel, 1][~fail] == st[~fail]).all(), "device PROPS differ from the oracle"
+            done += nd_c.shape[0]
+        out["cpu_baseline"] = {"value": binds / spent, "unit": "propagations/s", "cores": 1, "kind": "port",
+                               "nodes_per_s": done / spent,
+                               "sample": f"first {done} of the {B} instances of this run, {spent:.1f} s on one host core; "
+                                         f"device results re-checked against it bit for bit"}
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

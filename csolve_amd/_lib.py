@@ -1,0 +1,87 @@
+"""ctypes loader of libcsolve_hip.so (the product's only compute path)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcsolve_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "csolve_gpu.h")
+
+
+class CsolveError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"csolve_gpu error {code}: {message}")
+        self.code = code
+
+
+class Val(C.Structure):
+    _fields_ = [("lo", C.c_int32), ("hi", C.c_int32)]
+
+
+class Node(C.Structure):
+    _fields_ = [("var", C.c_int32), ("lo", C.c_int32), ("hi", C.c_int32), ("parent", C.c_int32)]
+
+
+class Result(C.Structure):
+    _fields_ = [("status", C.c_int32), ("props", C.c_int32), ("revisions", C.c_int32), ("rounds", C.c_int32)]
+
+
+def declared_symbols(header: str = HEADER_PATH):
+    """Names of every function declared in include/csolve_gpu.h."""
+    text = re.sub(r"/\*.*?\*/", "", open(header).read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(csgpu_\w+)\s*\(", text)))
+
+
+_lib = None
+
+
+def load_library():
+    """Load libcsolve_hip.so or raise -- there is nothing to fall back to."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C csolve_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # torch carries its own libamdhip64.so.7; load it first so the process has ONE HIP runtime
+    # and device pointers / streams handed over from torch belong to the runtime we launch on.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    L.csgpu_last_error.restype = C.c_char_p
+    L.csgpu_device_count.restype = C.c_int
+    L.csgpu_set_device.argtypes = [C.c_int]
+    L.csgpu_model_from_text.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
+    L.csgpu_model_from_file.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
+    L.csgpu_model_from_dump.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.csgpu_model_free.argtypes = [vp]
+    L.csgpu_model_free.restype = None
+    for f in ("csgpu_model_num_vars", "csgpu_model_num_clauses", "csgpu_model_objective",
+              "csgpu_model_objective_var"):
+        getattr(L, f).argtypes = [vp]
+    L.csgpu_model_var_name.argtypes = [vp, C.c_int]
+    L.csgpu_model_var_name.restype = C.c_char_p
+    L.csgpu_model_get_domains.argtypes = [vp, vp]
+    L.csgpu_model_set_domains.argtypes = [vp, vp]
+    L.csgpu_model_device_info.argtypes = [vp, C.POINTER(i64)]
+    L.csgpu_model_root_propagate.argtypes = [vp, C.POINTER(i32)]
+    L.csgpu_model_finalize.argtypes = [vp]
+    L.csgpu_model_build_tables.argtypes = [vp]
+    L.csgpu_propagate_batch.argtypes = [vp, vp, vp, vp, vp, i64, vp]
+    L.csgpu_eval_batch.argtypes = [vp, vp, vp, i64, vp]
+    L.csgpu_eval_clauses.argtypes = [vp, vp, vp, vp]
+    L.csgpu_propagate_one.argtypes = [vp, vp, Node, vp, C.POINTER(Result)]
+    _lib = L
+    return L
+
+
+def check(rc: int):
+    if rc < 0:
+        raise CsolveError(rc, load_library().csgpu_last_error().decode())
+    return rc

@@ -1,0 +1,382 @@
+/* cs_capi.hip -- implementation of the C ABI declared in include/csolve_gpu.h.
+ * Host orchestration only: parsing / indexing / table building happen in the C files
+ * next to this one, every interval computation happens in the kernels of
+ * cs_kernels.hip.h.  Nothing here evaluates or narrows a domain on the CPU. */
+#include <hip/hip_runtime.h>
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/csolve_gpu.h"
+#include "cs_kernels.hip.h"
+
+static thread_local char g_err[512] = "";
+
+static int set_err(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                          \
+  do {                                                                         \
+    hipError_t e_ = (expr);                                                    \
+    if (e_ != hipSuccess)                                                      \
+      return set_err(CSGPU_E_HIP, "%s: %s", #expr, hipGetErrorString(e_));     \
+  } while (0)
+
+struct csgpu_model {
+  cs_model *host;
+  int from_dump;     /* clause lists came with the file: keep them */
+  int finalized;
+  cs_dev_image *img; /* search image */
+  /* device copies of the image */
+  int *d_adj_off, *d_adj, *d_clause, *d_tree_off, *d_tnode, *d_tkid;
+  cs_tables tab;
+  size_t slice;      /* LDS bytes per node instance (16-byte aligned) */
+  int has_tree_adj;  /* some adjacency entry is a tree clause */
+  int n_cus;
+  /* staging of csgpu_propagate_one */
+  cs_val *d_one_in, *d_one_out;
+  cs_node_in *d_one_node;
+  cs_node_out *d_one_res;
+};
+
+extern "C" const char *csgpu_last_error(void) { return g_err; }
+
+extern "C" int csgpu_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) return set_err(CSGPU_E_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  return n;
+}
+
+extern "C" int csgpu_set_device(int device) {
+  HIP_TRY(hipSetDevice(device));
+  return CSGPU_OK;
+}
+
+/* ---- host model ------------------------------------------------------------------ */
+
+static int wrap_model(cs_model *host, int from_dump, csgpu_model **out) {
+  csgpu_model *m = (csgpu_model *)calloc(1, sizeof *m);
+  if (m == NULL) { cs_model_free(host); return set_err(CSGPU_E_ARG, "out of memory"); }
+  m->host = host;
+  m->from_dump = from_dump;
+  *out = m;
+  return CSGPU_OK;
+}
+
+extern "C" int csgpu_model_from_text(const char *text, int weights_on, csgpu_model **out) {
+  if (text == NULL || out == NULL) return set_err(CSGPU_E_ARG, "null argument");
+  char err[256];
+  cs_model *host = cs_model_parse(text, weights_on, err, sizeof err);
+  if (host == NULL) return set_err(CSGPU_E_PARSE, "%s", err);
+  return wrap_model(host, 0, out);
+}
+
+extern "C" int csgpu_model_from_file(const char *path, int weights_on, csgpu_model **out) {
+  if (path == NULL || out == NULL) return set_err(CSGPU_E_ARG, "null argument");
+  FILE *f = fopen(path, "rb");
+  if (f == NULL) return set_err(CSGPU_E_ARG, "%s: cannot open", path);
+  fseek(f, 0, SEEK_END);
+  long len = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  char *text = (char *)malloc((size_t)len + 1);
+  size_t got = fread(text, 1, (size_t)len, f);
+  fclose(f);
+  text[got] = '\0';
+  int rc = csgpu_model_from_text(text, weights_on, out);
+  free(text);
+  return rc;
+}
+
+extern "C" int csgpu_model_from_dump(const char *path, csgpu_model **out) {
+  if (path == NULL || out == NULL) return set_err(CSGPU_E_ARG, "null argument");
+  char err[256];
+  cs_model *host = cs_model_load(path, err, sizeof err);
+  if (host == NULL) return set_err(CSGPU_E_ARG, "%s", err);
+  if (host->clause_node == NULL) {
+    cs_model_free(host);
+    return set_err(CSGPU_E_ARG, "%s: model file has no clause index", path);
+  }
+  return wrap_model(host, 1, out);
+}
+
+static void free_device(csgpu_model *m) {
+  (void)hipFree(m->d_adj_off); (void)hipFree(m->d_adj); (void)hipFree(m->d_clause);
+  (void)hipFree(m->d_tree_off); (void)hipFree(m->d_tnode); (void)hipFree(m->d_tkid);
+  (void)hipFree(m->d_one_in); (void)hipFree(m->d_one_out); (void)hipFree(m->d_one_node); (void)hipFree(m->d_one_res);
+  m->d_adj_off = m->d_adj = m->d_clause = m->d_tree_off = m->d_tnode = m->d_tkid = NULL;
+  m->d_one_in = m->d_one_out = NULL;
+  m->d_one_node = NULL;
+  m->d_one_res = NULL;
+  cs_dev_image_free(m->img);
+  m->img = NULL;
+}
+
+extern "C" void csgpu_model_free(csgpu_model *m) {
+  if (m == NULL) return;
+  free_device(m);
+  cs_model_free(m->host);
+  free(m);
+}
+
+extern "C" int csgpu_model_num_vars(const csgpu_model *m) { return m ? m->host->n_vars : CSGPU_E_ARG; }
+extern "C" int csgpu_model_num_clauses(const csgpu_model *m) { return m ? m->host->n_clauses : CSGPU_E_ARG; }
+extern "C" int csgpu_model_objective(const csgpu_model *m) { return m ? m->host->objective : CSGPU_E_ARG; }
+extern "C" int csgpu_model_objective_var(const csgpu_model *m) { return m ? m->host->obj_var : CSGPU_E_ARG; }
+
+extern "C" const char *csgpu_model_var_name(const csgpu_model *m, int var) {
+  if (m == NULL || var < 0 || var >= m->host->n_vars) return NULL;
+  return m->host->names[var];
+}
+
+extern "C" int csgpu_model_get_domains(const csgpu_model *m, csgpu_val *out) {
+  if (m == NULL || out == NULL) return set_err(CSGPU_E_ARG, "null argument");
+  memcpy(out, m->host->dom, (size_t)m->host->n_vars * sizeof(cs_val));
+  return CSGPU_OK;
+}
+
+extern "C" int csgpu_model_set_domains(csgpu_model *m, const csgpu_val *in) {
+  if (m == NULL || in == NULL) return set_err(CSGPU_E_ARG, "null argument");
+  memcpy(m->host->dom, in, (size_t)m->host->n_vars * sizeof(cs_val));
+  return CSGPU_OK;
+}
+
+extern "C" int csgpu_model_device_info(const csgpu_model *m, int64_t info[8]) {
+  if (m == NULL || info == NULL) return set_err(CSGPU_E_ARG, "null argument");
+  if (m->img == NULL) return set_err(CSGPU_E_STATE, "device tables are not built");
+  info[0] = m->img->n_adj;
+  info[1] = m->img->n_ne;
+  info[2] = m->img->n_tree_clauses;
+  info[3] = m->img->n_tnodes;
+  info[4] = (int64_t)m->slice;
+  info[5] = m->img->max_list;
+  info[6] = m->img->n_skip;
+  info[7] = m->img->max_tree;
+  return CSGPU_OK;
+}
+
+/* ---- device image ------------------------------------------------------------------ */
+
+struct dev_tables_owner {
+  int *adj_off, *adj, *clause, *tree_off, *tnode, *tkid;
+};
+
+static int upload(const void *src, size_t bytes, int **dst) {
+  HIP_TRY(hipMalloc((void **)dst, bytes ? bytes : 16));
+  if (bytes) HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+  return CSGPU_OK;
+}
+
+static int upload_image(const cs_dev_image *g, dev_tables_owner *o, cs_tables *t) {
+  int rc;
+  memset(o, 0, sizeof *o);
+  if ((rc = upload(g->adj_off, ((size_t)g->n_vars + 1) * 4, &o->adj_off))) return rc;
+  if ((rc = upload(g->adj, (size_t)(g->n_adj ? g->n_adj : 1) * 8, &o->adj))) return rc;
+  if ((rc = upload(g->clause, (size_t)(g->n_clauses ? g->n_clauses : 1) * 16, &o->clause))) return rc;
+  if ((rc = upload(g->tree_off, ((size_t)g->n_trees + 1) * 4, &o->tree_off))) return rc;
+  if ((rc = upload(g->tnode, (size_t)(g->n_tnodes ? g->n_tnodes : 1) * 16, &o->tnode))) return rc;
+  if ((rc = upload(g->tkid, (size_t)(g->n_tkids ? g->n_tkids : 1) * 4, &o->tkid))) return rc;
+  t->n_vars = g->n_vars;
+  t->n_clauses = g->n_clauses;
+  t->n_words = (g->n_vars + 31) / 32;
+  t->adj_off = o->adj_off;
+  t->adj = (const int2 *)o->adj;
+  t->clause = (const int4 *)o->clause;
+  t->tree_off = o->tree_off;
+  t->tnode = (const int4 *)o->tnode;
+  t->tkid = o->tkid;
+  return CSGPU_OK;
+}
+
+static void free_tables(dev_tables_owner *o) {
+  (void)hipFree(o->adj_off); (void)hipFree(o->adj); (void)hipFree(o->clause);
+  (void)hipFree(o->tree_off); (void)hipFree(o->tnode); (void)hipFree(o->tkid);
+}
+
+static int lds_limit(size_t bytes, const void *func) {
+  if (bytes > 160u * 1024u) return set_err(CSGPU_E_LIMIT, "%zu bytes of LDS per workgroup exceed the 160 KiB of a CU", bytes);
+  if (bytes > 48u * 1024u)
+    HIP_TRY(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return CSGPU_OK;
+}
+
+/* ---- root phase -------------------------------------------------------------------- */
+
+extern "C" int csgpu_model_root_propagate(csgpu_model *m, int32_t *status) {
+  if (m == NULL || status == NULL) return set_err(CSGPU_E_ARG, "null argument");
+  cs_model *h = m->host;
+  if (h->root < 0) return set_err(CSGPU_E_STATE, "model has no root");
+  if (!m->from_dump && cs_model_index(h) != 0) return set_err(CSGPU_E_ARG, "%s", h->err);
+  char err[200];
+  cs_dev_image *g = cs_dev_image_build(h, 0, err, sizeof err);
+  if (g == NULL) return set_err(CSGPU_E_LIMIT, "%s", err);
+
+  dev_tables_owner own;
+  cs_tables tab;
+  int rc = upload_image(g, &own, &tab);
+  cs_val *d_in = NULL, *d_out = NULL;
+  cs_node_out *d_res = NULL;
+  cs_node_out res;
+  const size_t nbytes = (size_t)(h->n_vars ? h->n_vars : 1) * sizeof(cs_val);
+  const size_t lds = (size_t)h->n_vars * sizeof(cs_val) + 4 * sizeof(unsigned);
+  hipError_t e = hipSuccess;
+  if (rc == CSGPU_OK) rc = lds_limit(lds, (const void *)cs_propagate_sweeps);
+  if (rc == CSGPU_OK) {
+    if ((e = hipMalloc((void **)&d_in, nbytes)) != hipSuccess || (e = hipMalloc((void **)&d_out, nbytes)) != hipSuccess ||
+        (e = hipMalloc((void **)&d_res, sizeof res)) != hipSuccess ||
+        (e = hipMemcpy(d_in, h->dom, (size_t)h->n_vars * sizeof(cs_val), hipMemcpyHostToDevice)) != hipSuccess)
+      rc = set_err(CSGPU_E_HIP, "root propagate setup: %s", hipGetErrorString(e));
+  }
+  if (rc == CSGPU_OK) {
+    hipLaunchKernelGGL(cs_propagate_sweeps, dim3(1), dim3(CS_BLOCK), lds, 0, tab, d_in, d_out, d_res, 0x7fffffff);
+    if ((e = hipGetLastError()) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess ||
+        (e = hipMemcpy(&res, d_res, sizeof res, hipMemcpyDeviceToHost)) != hipSuccess ||
+        (e = hipMemcpy(h->dom, d_out, (size_t)h->n_vars * sizeof(cs_val), hipMemcpyDeviceToHost)) != hipSuccess)
+      rc = set_err(CSGPU_E_HIP, "root propagate: %s", hipGetErrorString(e));
+    else
+      *status = res.status < 0 ? -1 : res.props;
+  }
+  (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_res);
+  free_tables(&own);
+  cs_dev_image_free(g);
+  return rc;
+}
+
+/* ---- finalize ---------------------------------------------------------------------- */
+
+extern "C" int csgpu_model_build_tables(csgpu_model *m) {
+  if (m == NULL) return set_err(CSGPU_E_ARG, "null argument");
+  cs_model *h = m->host;
+  int32_t ub = cs_model_first_unbounded(h);
+  if (ub >= 0) return set_err(CSGPU_E_UNBOUNDED, "unbounded variable: %s", h->names[ub]);
+  if (!m->from_dump && cs_model_index(h) != 0) return set_err(CSGPU_E_ARG, "%s", h->err);
+  cs_dev_image_free(m->img);
+  m->img = NULL;
+  m->finalized = 0;
+  char err[200];
+  m->img = cs_dev_image_build(h, 1, err, sizeof err);
+  if (m->img == NULL) return set_err(CSGPU_E_LIMIT, "%s", err);
+  const size_t slice = (size_t)h->n_vars * sizeof(cs_val) + 2 * (size_t)((h->n_vars + 31) / 32) * sizeof(unsigned);
+  m->slice = (slice + 15) & ~(size_t)15;
+  return CSGPU_OK;
+}
+
+extern "C" int csgpu_model_finalize(csgpu_model *m) {
+  if (m == NULL) return set_err(CSGPU_E_ARG, "null argument");
+  cs_model *h = m->host;
+  free_device(m);
+  int rc0 = csgpu_model_build_tables(m);
+  if (rc0 != CSGPU_OK) return rc0;
+
+  dev_tables_owner own;
+  int rc = upload_image(m->img, &own, &m->tab);
+  m->d_adj_off = own.adj_off; m->d_adj = own.adj; m->d_clause = own.clause;
+  m->d_tree_off = own.tree_off; m->d_tnode = own.tnode; m->d_tkid = own.tkid;
+  if (rc != CSGPU_OK) return rc;
+
+  const size_t slice = (size_t)h->n_vars * sizeof(cs_val) + 2 * (size_t)m->tab.n_words * sizeof(unsigned);
+  m->slice = (slice + 15) & ~(size_t)15;
+  m->has_tree_adj = 0;
+  for (int32_t i = 0; i < m->img->n_adj; i++)
+    if (m->img->adj[2 * i] < 0) { m->has_tree_adj = 1; break; }
+  const size_t lds = m->slice * CS_WAVES_PER_BLOCK;
+  if ((rc = lds_limit(lds, (const void *)cs_propagate_events<false>))) return rc;
+  if ((rc = lds_limit(lds, (const void *)cs_propagate_events<true>))) return rc;
+  if ((rc = lds_limit((size_t)h->n_vars * sizeof(cs_val) + 16, (const void *)cs_eval_root))) return rc;
+  if ((rc = lds_limit((size_t)h->n_vars * sizeof(cs_val) + 16, (const void *)cs_eval_clauses))) return rc;
+
+  int dev = 0;
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDevice(&dev));
+  HIP_TRY(hipGetDeviceProperties(&prop, dev));
+  m->n_cus = prop.multiProcessorCount;
+
+  const size_t nbytes = (size_t)(h->n_vars ? h->n_vars : 1) * sizeof(cs_val);
+  HIP_TRY(hipMalloc((void **)&m->d_one_in, nbytes));
+  HIP_TRY(hipMalloc((void **)&m->d_one_out, nbytes));
+  HIP_TRY(hipMalloc((void **)&m->d_one_node, sizeof(cs_node_in)));
+  HIP_TRY(hipMalloc((void **)&m->d_one_res, sizeof(cs_node_out)));
+  m->finalized = 1;
+  return CSGPU_OK;
+}
+
+/* ---- batched propagation ----------------------------------------------------------- */
+
+extern "C" int csgpu_propagate_batch(const csgpu_model *m, const csgpu_val *d_states_in, const csgpu_node *d_nodes,
+                                     csgpu_val *d_states_out, csgpu_result *d_results, int64_t batch, void *stream) {
+  if (m == NULL || d_states_in == NULL || d_nodes == NULL || d_states_out == NULL || d_results == NULL || batch < 0)
+    return set_err(CSGPU_E_ARG, "null argument");
+  if (!m->finalized) return set_err(CSGPU_E_STATE, "model is not finalized");
+  if (batch == 0) return CSGPU_OK;
+  const size_t lds = m->slice * CS_WAVES_PER_BLOCK;
+  /* resident workgroups per CU: LDS- and wave-slot-limited (32 waves per CU) */
+  size_t per_cu = (160u * 1024u) / lds;
+  if (per_cu > 32 / CS_WAVES_PER_BLOCK) per_cu = 32 / CS_WAVES_PER_BLOCK;
+  if (per_cu < 1) per_cu = 1;
+  int64_t blocks = (batch + CS_WAVES_PER_BLOCK - 1) / CS_WAVES_PER_BLOCK;
+  const int64_t resident = (int64_t)m->n_cus * (int64_t)per_cu;
+  /* enough workgroups to fill the chip several times over, the rest by grid stride */
+  if (blocks > resident * 4) blocks = resident * 4;
+  hipStream_t s = (hipStream_t)stream;
+  const cs_val *in = (const cs_val *)d_states_in;
+  const cs_node_in *nodes = (const cs_node_in *)d_nodes;
+  cs_val *out = (cs_val *)d_states_out;
+  cs_node_out *res = (cs_node_out *)d_results;
+  if (m->has_tree_adj)
+    hipLaunchKernelGGL(cs_propagate_events<true>, dim3((unsigned)blocks), dim3(CS_BLOCK), lds, s, m->tab, in, nodes, out,
+                       res, (long long)batch);
+  else
+    hipLaunchKernelGGL(cs_propagate_events<false>, dim3((unsigned)blocks), dim3(CS_BLOCK), lds, s, m->tab, in, nodes, out,
+                       res, (long long)batch);
+  HIP_TRY(hipGetLastError());
+  return CSGPU_OK;
+}
+
+extern "C" int csgpu_eval_batch(const csgpu_model *m, const csgpu_val *d_states, int32_t *d_truth, int64_t batch,
+                                void *stream) {
+  if (m == NULL || d_states == NULL || d_truth == NULL || batch < 0) return set_err(CSGPU_E_ARG, "null argument");
+  if (!m->finalized) return set_err(CSGPU_E_STATE, "model is not finalized");
+  if (batch == 0) return CSGPU_OK;
+  if (batch > 0x7fffffff) return set_err(CSGPU_E_LIMIT, "batch too large");
+  const size_t lds = (size_t)m->host->n_vars * sizeof(cs_val) + 16;
+  hipLaunchKernelGGL(cs_eval_root, dim3((unsigned)batch), dim3(CS_BLOCK), lds, (hipStream_t)stream, m->tab,
+                     (const cs_val *)d_states, d_truth);
+  HIP_TRY(hipGetLastError());
+  return CSGPU_OK;
+}
+
+extern "C" int csgpu_eval_clauses(const csgpu_model *m, const csgpu_val *d_state, csgpu_val *d_vals, void *stream) {
+  if (m == NULL || d_state == NULL || d_vals == NULL) return set_err(CSGPU_E_ARG, "null argument");
+  if (!m->finalized) return set_err(CSGPU_E_STATE, "model is not finalized");
+  if (m->host->n_clauses == 0) return CSGPU_OK;
+  const size_t lds = (size_t)m->host->n_vars * sizeof(cs_val) + 16;
+  unsigned blocks = (unsigned)((m->host->n_clauses + CS_BLOCK - 1) / CS_BLOCK);
+  if (blocks > 1024u) blocks = 1024u;
+  hipLaunchKernelGGL(cs_eval_clauses, dim3(blocks), dim3(CS_BLOCK), lds, (hipStream_t)stream, m->tab,
+                     (const cs_val *)d_state, (cs_val *)d_vals);
+  HIP_TRY(hipGetLastError());
+  return CSGPU_OK;
+}
+
+extern "C" int csgpu_propagate_one(const csgpu_model *m, const csgpu_val *state, csgpu_node node, csgpu_val *state_out,
+                                   csgpu_result *result) {
+  if (m == NULL || state == NULL || state_out == NULL || result == NULL) return set_err(CSGPU_E_ARG, "null argument");
+  if (!m->finalized) return set_err(CSGPU_E_STATE, "model is not finalized");
+  const size_t nbytes = (size_t)m->host->n_vars * sizeof(cs_val);
+  node.parent = 0;
+  HIP_TRY(hipMemcpy(m->d_one_in, state, nbytes, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(m->d_one_node, &node, sizeof node, hipMemcpyHostToDevice));
+  int rc = csgpu_propagate_batch(m, (const csgpu_val *)m->d_one_in, (const csgpu_node *)m->d_one_node,
+                                 (csgpu_val *)m->d_one_out, (csgpu_result *)m->d_one_res, 1, NULL);
+  if (rc != CSGPU_OK) return rc;
+  HIP_TRY(hipMemcpy(result, m->d_one_res, sizeof *result, hipMemcpyDeviceToHost));
+  if (result->status >= 0) HIP_TRY(hipMemcpy(state_out, m->d_one_out, nbytes, hipMemcpyDeviceToHost));
+  return CSGPU_OK;
+}

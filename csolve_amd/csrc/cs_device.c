@@ -1,0 +1,201 @@
+/* cs_device.c -- host-side construction of the device image (see cs_device.h). */
+#include "cs_device.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define NE_LIMIT (1 << 30) /* magnitudes below this cannot saturate when two are added */
+
+typedef struct {
+  int32_t *v;
+  int32_t n, cap;
+} ibuf;
+
+static void ibuf_push(ibuf *b, int32_t x) {
+  if (b->n == b->cap) {
+    b->cap = b->cap ? b->cap * 2 : 256;
+    b->v = (int32_t *)realloc(b->v, (size_t)b->cap * sizeof(int32_t));
+    if (b->v == NULL) { fprintf(stderr, "csolve_amd: error: out of memory\n"); exit(EXIT_FAILURE); }
+  }
+  b->v[b->n++] = x;
+}
+
+static int small(int64_t x) { return x > -(int64_t)NE_LIMIT && x < (int64_t)NE_LIMIT; }
+
+/* a sub-tree without variables that is a single small constant */
+static int const_value(const cs_model *m, int32_t node, int64_t *c) {
+  const cs_node *n = &m->nodes[node];
+  if (n->op == CS_OP_CONST && n->a == n->b && small(n->a)) { *c = n->a; return 1; }
+  if (n->op == CS_OP_NEG && const_value(m, n->a, c)) { *c = -*c; return 1; }
+  return 0;
+}
+
+/* node == X_var + k with everything small */
+static int affine(const cs_model *m, int32_t node, int32_t *var, int64_t *k) {
+  const cs_node *n = &m->nodes[node];
+  if (n->op == CS_OP_VAR) {
+    cs_val d = m->dom[n->a];
+    if (!small(d.lo) || !small(d.hi)) return 0;
+    *var = n->a; *k = 0;
+    return 1;
+  }
+  if (n->op == CS_OP_ADD) {
+    int64_t c;
+    if (const_value(m, n->b, &c) && affine(m, n->a, var, k)) { *k += c; return small(*k); }
+    if (const_value(m, n->a, &c) && affine(m, n->b, var, k)) { *k += c; return small(*k); }
+  }
+  return 0;
+}
+
+static int match_ne(const cs_model *m, int32_t root, int32_t *a, int32_t *b, int32_t *d) {
+  const cs_node *n = &m->nodes[root];
+  if (n->op != CS_OP_NOT) return 0;
+  const cs_node *e = &m->nodes[n->a];
+  if (e->op != CS_OP_EQ) return 0;
+  int64_t ka, kb;
+  if (!affine(m, e->a, a, &ka) || !affine(m, e->b, b, &kb) || *a == *b) return 0;
+  if (!small(kb - ka)) return 0;
+  *d = (int32_t)(kb - ka);
+  return 1;
+}
+
+typedef struct {
+  const cs_model *m;
+  ibuf tnode, tkid;
+  int32_t *local;   /* node id -> local index in the tree being built, -1 = not yet */
+  ibuf touched;
+  int32_t base;     /* first tnode index of the current tree */
+  int bad;
+} tree_ctx;
+
+static int32_t emit_tree(tree_ctx *t, int32_t node) {
+  if (t->local[node] >= 0) return t->local[node];
+  const cs_node *n = &t->m->nodes[node];
+  int32_t a = n->a, b = n->b;
+  switch (n->op) {
+  case CS_OP_VAR: case CS_OP_CONST:
+    break;
+  case CS_OP_NEG: case CS_OP_NOT:
+    a = emit_tree(t, n->a); b = -1;
+    break;
+  case CS_OP_EQ: case CS_OP_LT: case CS_OP_ADD: case CS_OP_MUL: case CS_OP_AND: case CS_OP_OR:
+    a = emit_tree(t, n->a);
+    b = emit_tree(t, t->m->nodes[node].b);
+    break;
+  case CS_OP_WAND: {
+    int32_t cnt = n->b, off = n->a;
+    int32_t *loc = (int32_t *)malloc((size_t)(cnt ? cnt : 1) * sizeof(int32_t));
+    for (int32_t i = 0; i < cnt; i++) loc[i] = emit_tree(t, t->m->kids[off + i]);
+    a = t->tkid.n;
+    for (int32_t i = 0; i < cnt; i++) ibuf_push(&t->tkid, loc[i]);
+    b = cnt;
+    free(loc);
+    break;
+  }
+  default:
+    t->bad = 1;
+    break;
+  }
+  int32_t idx = t->tnode.n / 4 - t->base;
+  ibuf_push(&t->tnode, t->m->nodes[node].op);
+  ibuf_push(&t->tnode, a);
+  ibuf_push(&t->tnode, b);
+  ibuf_push(&t->tnode, 0);
+  t->local[node] = idx;
+  ibuf_push(&t->touched, node);
+  return idx;
+}
+
+void cs_dev_image_free(cs_dev_image *g) {
+  if (g == NULL) return;
+  free(g->adj_off); free(g->adj); free(g->clause); free(g->tree_off); free(g->tnode); free(g->tkid);
+  free(g);
+}
+
+cs_dev_image *cs_dev_image_build(const cs_model *m, int with_lists, char *err, size_t errlen) {
+  if (m->clause_node == NULL || (with_lists && m->list_off == NULL)) {
+    if (err) snprintf(err, errlen, "model has no clause index");
+    return NULL;
+  }
+  cs_dev_image *g = (cs_dev_image *)calloc(1, sizeof *g);
+  g->n_vars = m->n_vars;
+  g->n_clauses = m->n_clauses;
+  g->clause = (int32_t *)calloc((size_t)(m->n_clauses ? m->n_clauses : 1) * 4, sizeof(int32_t));
+
+  tree_ctx t;
+  memset(&t, 0, sizeof t);
+  t.m = m;
+  t.local = (int32_t *)malloc((size_t)(m->n_nodes ? m->n_nodes : 1) * sizeof(int32_t));
+  for (int32_t i = 0; i < m->n_nodes; i++) t.local[i] = -1;
+  ibuf tree_off = { 0 };
+
+  for (int32_t c = 0; c < m->n_clauses; c++) {
+    int32_t root = m->clause_node[c];
+    const cs_node *rn = &m->nodes[root];
+    int32_t *rec = &g->clause[4 * c];
+    int32_t a, b, d;
+    if (rn->op == CS_OP_CONST && rn->a <= 1 && rn->b >= 1 && rn->a == rn->b) {
+      rec[0] = CS_CL_SKIP;
+      g->n_skip++;
+    } else if (match_ne(m, root, &a, &b, &d)) {
+      rec[0] = CS_CL_NE; rec[1] = a; rec[2] = b; rec[3] = d;
+      g->n_ne++;
+    } else {
+      ibuf_push(&tree_off, t.tnode.n / 4);
+      t.base = t.tnode.n / 4;
+      t.touched.n = 0;
+      emit_tree(&t, root);
+      int32_t len = t.tnode.n / 4 - t.base;
+      for (int32_t i = 0; i < t.touched.n; i++) t.local[t.touched.v[i]] = -1;
+      if (len > g->max_tree) g->max_tree = len;
+      rec[0] = CS_CL_TREE; rec[1] = g->n_trees;
+      g->n_trees++;
+      g->n_tree_clauses++;
+    }
+  }
+  ibuf_push(&tree_off, t.tnode.n / 4);
+  g->tree_off = tree_off.v;
+  g->tnode = t.tnode.v ? t.tnode.v : (int32_t *)calloc(4, sizeof(int32_t));
+  g->n_tnodes = t.tnode.n / 4;
+  g->tkid = t.tkid.v ? t.tkid.v : (int32_t *)calloc(1, sizeof(int32_t));
+  g->n_tkids = t.tkid.n;
+  free(t.local);
+  free(t.touched.v);
+
+  if (t.bad) {
+    if (err) snprintf(err, errlen, "constraint type without a device implementation (conflict clause)");
+    cs_dev_image_free(g);
+    return NULL;
+  }
+  if (g->max_tree > CS_MAX_TREE_NODES) {
+    if (err) snprintf(err, errlen, "a clause has %d nodes, device limit is %d", g->max_tree, CS_MAX_TREE_NODES);
+    cs_dev_image_free(g);
+    return NULL;
+  }
+
+  g->adj_off = (int32_t *)calloc((size_t)m->n_vars + 1, sizeof(int32_t));
+  if (with_lists) {
+    ibuf adj = { 0 };
+    for (int32_t v = 0; v < m->n_vars; v++) {
+      g->adj_off[v] = adj.n / 2;
+      for (int32_t i = m->list_off[v]; i < m->list_off[v + 1]; i++) {
+        const int32_t *rec = &g->clause[4 * m->list[i]];
+        if (rec[0] == CS_CL_NE) {
+          if (rec[1] == v) { ibuf_push(&adj, rec[2]); ibuf_push(&adj, rec[3]); }
+          else { ibuf_push(&adj, rec[1]); ibuf_push(&adj, -rec[3]); }
+        } else if (rec[0] == CS_CL_TREE) {
+          ibuf_push(&adj, ~rec[1]); ibuf_push(&adj, 0);
+        }
+      }
+      int32_t len = adj.n / 2 - g->adj_off[v];
+      if (len > g->max_list) g->max_list = len;
+    }
+    g->adj_off[m->n_vars] = adj.n / 2;
+    g->n_adj = adj.n / 2;
+    g->adj = adj.v ? adj.v : (int32_t *)calloc(2, sizeof(int32_t));
+  } else {
+    g->adj = (int32_t *)calloc(2, sizeof(int32_t));
+  }
+  return g;
+}

@@ -1,0 +1,71 @@
+/* cs_device.h -- the immutable device image of a problem: what the HIP kernels read.
+ *
+ * Built on the host from a cs_model (cs_device.c), uploaded once, shared by every
+ * node instance of every launch.  All arrays are int32.
+ *
+ * Two views of the same clause set:
+ *
+ *  (1) clause-centric, for full sweeps (root phase, reference propagate.c:474-485 /
+ *      379-392) and for evaluating the root (eval.c:233-255):
+ *        clause[4*c .. 4*c+3] = { kind, a, b, d }
+ *          CS_CL_SKIP  constant-true element, never narrows, never fails
+ *          CS_CL_NE    X_a != X_b + d   (binary fast path, see below)
+ *          CS_CL_TREE  general expression tree, a = tree id
+ *
+ *  (2) variable-centric, for the event-driven fixpoint (propagate.c:488-538):
+ *        adj_off[v] .. adj_off[v+1]   entries {x, y} of variable v, in the order of
+ *        the reference's per-variable clause list (parser_support.c:338-396)
+ *          x >= 0 : binary NE seen from v:  X_v != X_x + y
+ *          x <  0 : tree clause, tree id = ~x
+ *
+ * Binary fast path.  A clause NOT(EQ(L, R)) where L and R are each `VAR` or
+ * `VAR + constant` (constant on either side of the ADD, possibly written as a NEG of
+ * a constant) over two different variables is stored as X_a != X_b + d.  It is only
+ * chosen when every bound and constant involved is below 2^30 in magnitude, so that
+ * none of the reference's saturating additions (arith.c:38-51) can saturate and the
+ * record is exactly equivalent to revising the tree through propagate_not ->
+ * propagate_eq(false) -> propagate_add -> propagate_term (propagate.c:289-301, 123-136,
+ * 106-120, 223-246, 57-87).
+ *
+ * Trees.  tree_off[t] .. tree_off[t+1] index tnode[], 4 ints per node { op, a, b, 0 } in
+ * post-order (children before parents, the root last); child references are indices local
+ * to the tree; VAR: a = variable; CONST: a = lo, b = hi; WAND: a = offset into tkid[],
+ * b = count, tkid[] holds local indices.
+ */
+#ifndef CS_DEVICE_H
+#define CS_DEVICE_H
+
+#include "cs_model.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { CS_CL_SKIP = 0, CS_CL_NE = 1, CS_CL_TREE = 2 };
+
+/* largest tree a device lane can revise (per-lane value scratch), and the deepest
+ * pending-push stack it keeps */
+#define CS_MAX_TREE_NODES 256
+
+typedef struct cs_dev_image {
+  int32_t n_vars, n_clauses;
+  int32_t n_adj;        /* adjacency entries */
+  int32_t n_ne, n_tree_clauses, n_skip;
+  int32_t max_list;     /* longest per-variable list */
+  int32_t *adj_off;     /* [n_vars+1] */
+  int32_t *adj;         /* [2*n_adj] */
+  int32_t *clause;      /* [4*n_clauses] */
+  int32_t n_trees, n_tnodes, n_tkids, max_tree;
+  int32_t *tree_off;    /* [n_trees+1] */
+  int32_t *tnode;       /* [4*n_tnodes] */
+  int32_t *tkid;        /* [n_tkids] */
+} cs_dev_image;
+
+/* with_lists = 0: clause-centric view only (root phase, lists not needed) */
+cs_dev_image *cs_dev_image_build(const cs_model *m, int with_lists, char *err, size_t errlen);
+void cs_dev_image_free(cs_dev_image *img);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

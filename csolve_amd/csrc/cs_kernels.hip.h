@@ -1,0 +1,515 @@
+/* cs_kernels.hip.h -- gfx950 kernels of the constraint-propagation fixpoint.
+ *
+ * Written for CDNA4 only: 64-lane wavefronts, LDS-resident node state, wave-level
+ * ballots.  No MFMA: the work is integer compare / select / LDS atomics.
+ *
+ * Execution model of the hot kernel (cs_propagate_events):
+ *   - one WAVEFRONT owns one search node; a 256-thread workgroup is four independent
+ *     nodes, there is no __syncthreads() anywhere in the kernel;
+ *   - the node's interval domains (n_vars x {lo,hi}, 8 B each, the reference's
+ *     `struct val_t`) live in that wave's slice of LDS for the whole fixpoint and are
+ *     read from / written to HBM exactly once, 8 B per lane, fully coalesced;
+ *   - the worklist is a bit mask of changed variables in LDS (two buffers, swapped per
+ *     round); the wave walks the set bits with scalar code, and for each changed
+ *     variable its 64 lanes stride over that variable's adjacency list (the reference's
+ *     per-variable clause list), revising 64 clauses per step;
+ *   - narrowing is ds_max_rtn_i32 / ds_min_rtn_i32 on the bounds (LDS atomics), so several
+ *     clauses may tighten one variable in the same step; the returned old value tells
+ *     which lane actually narrowed (that lane counts the propagation and sets the
+ *     variable's bit for the next round);
+ *   - failure (an empty interval) is detected by the narrowing lane when it can see it
+ *     and, for racing lo/hi updates, when the variable is popped in the next round.
+ *
+ * Reference semantics restated here (one clause revision):
+ *   propagate_clauses   propagate.c:488-538   -> rounds over the changed-variable mask
+ *   propagate_term      propagate.c:57-87     -> cs_ctx::narrow
+ *   propagate_eq/lt/neg/add/mul/not/and/or/wand  propagate.c:139-392 -> cs_tree_revise
+ *   eval_*              eval.c:27-255         -> cs_tree_eval (+ cs_arith.h)
+ *   NOT(EQ(x+k, y+l))   propagate.c:289-301,123-136,106-120,223-246 -> cs_ne_revise
+ * The revision ORDER differs from the reference (parallel rounds instead of depth-first
+ * recursion); the fixpoint and the consistent/inconsistent verdict do not.
+ */
+#ifndef CS_KERNELS_HIP_H
+#define CS_KERNELS_HIP_H
+
+#include <hip/hip_runtime.h>
+
+#include "cs_arith.h"
+#include "cs_device.h"
+#include "cs_frontend.h"
+
+#define CS_WAVE 64
+#define CS_WAVES_PER_BLOCK 4
+#define CS_BLOCK (CS_WAVE * CS_WAVES_PER_BLOCK)
+
+struct cs_tables {
+  int n_vars, n_clauses, n_words; /* n_words = ceil(n_vars / 32) */
+  const int *adj_off;
+  const int2 *adj;
+  const int4 *clause;
+  const int *tree_off;
+  const int4 *tnode;
+  const int *tkid;
+};
+
+struct cs_node_in {
+  int var, lo, hi, parent;
+};
+struct cs_node_out {
+  int status, props, revisions, rounds;
+};
+
+/* compiler-level ordering between LDS accesses of different lanes of one wave: the
+ * hardware already executes a wave's DS instructions in order */
+__device__ __forceinline__ void cs_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+/* per-lane view of the node a wave (or block) is working on */
+struct cs_ctx {
+  cs_val *dom;        /* LDS, [n_vars] */
+  unsigned *mark;     /* LDS, next-round changed mask (events) or one flag word (sweeps) */
+  int mark_is_flag;
+  int fail, props, revisions;
+
+  __device__ __forceinline__ void touched(int v) {
+    if (mark_is_flag) mark[0] = 1u;
+    else atomicOr(&mark[v >> 5], 1u << (v & 31));
+  }
+  __device__ __forceinline__ void raise_lo(int v, int lo) {
+    int old = atomicMax(&dom[v].lo, lo);
+    if (old < lo) {
+      props++;
+      touched(v);
+      if (lo > dom[v].hi) fail = 1;
+    }
+  }
+  __device__ __forceinline__ void lower_hi(int v, int hi) {
+    int old = atomicMin(&dom[v].hi, hi);
+    if (old > hi) {
+      props++;
+      touched(v);
+      if (hi < dom[v].lo) fail = 1;
+    }
+  }
+  /* propagate_term (propagate.c:57-87): intersect dom[v] with want */
+  __device__ __forceinline__ void narrow(int v, cs_val want) {
+    cs_val d = dom[v];
+    if (d.lo > want.hi || d.hi < want.lo) { fail = 1; return; }
+    int before = props;
+    if (want.lo > d.lo) raise_lo(v, want.lo);
+    if (want.hi < d.hi) lower_hi(v, want.hi);
+    /* the reference binds lo and hi in one step: count one propagation */
+    if (props == before + 2) props = before + 1;
+  }
+};
+
+/* X_u != X_w + d seen from u (both directions of the clause, propagate.c:123-136) */
+__device__ __forceinline__ void cs_ne_revise(cs_ctx &cx, int u, int w, int d) {
+  cs_val du = cx.dom[u], dw = cx.dom[w];
+  cx.revisions++;
+  if (du.lo == du.hi) { /* u is a value: w must avoid f */
+    int f = du.lo - d;
+    if (dw.lo == f) cx.raise_lo(w, f + 1);
+    else if (dw.hi == f) cx.lower_hi(w, f - 1);
+  }
+  if (dw.lo == dw.hi) { /* w is a value: u must avoid f */
+    int f = dw.lo + d;
+    if (du.lo == f) cx.raise_lo(u, f + 1);
+    else if (du.hi == f) cx.lower_hi(u, f - 1);
+  }
+}
+
+/* ---- general expression trees ------------------------------------------------ */
+
+/* bottom-up interval evaluation of every node of one tree (eval.c:27-255) */
+__device__ inline void cs_tree_eval(const cs_tables &T, const int4 *nd, int len, const cs_val *dom, cs_val *val) {
+  for (int k = 0; k < len; k++) {
+    int4 n = nd[k];
+    cs_val r;
+    switch (n.x) {
+    case CS_OP_VAR: r = dom[n.y]; break;
+    case CS_OP_CONST: r = cs_interval(n.y, n.z); break;
+    case CS_OP_EQ: r = cs_ev_eq(val[n.y], val[n.z]); break;
+    case CS_OP_LT: r = cs_ev_lt(val[n.y], val[n.z]); break;
+    case CS_OP_NEG: r = cs_ev_neg(val[n.y]); break;
+    case CS_OP_ADD: r = cs_ev_add(val[n.y], val[n.z]); break;
+    case CS_OP_MUL: r = cs_ev_mul(val[n.y], val[n.z]); break;
+    case CS_OP_NOT: r = cs_ev_not(val[n.y]); break;
+    case CS_OP_AND: r = cs_ev_and(val[n.y], val[n.z]); break;
+    case CS_OP_OR: r = cs_ev_or(val[n.y], val[n.z]); break;
+    case CS_OP_WAND: { /* eval.c:233-255 */
+      int any_false = 0, all_true = 1;
+      for (int i = 0; i < n.z; i++) {
+        cs_val c = val[T.tkid[n.y + i]];
+        any_false |= cs_is_false(c);
+        all_true &= cs_is_true(c);
+      }
+      r = cs_tv(all_true && !any_false, any_false);
+      break;
+    }
+    default: r = cs_interval(0, 1); break;
+    }
+    val[k] = r;
+  }
+}
+
+struct cs_tree_scratch {
+  cs_val val[CS_MAX_TREE_NODES];
+  cs_val want[CS_MAX_TREE_NODES];
+  short node[CS_MAX_TREE_NODES];
+};
+
+/* One revision of a tree clause: evaluate every node, then push `true` down from the
+ * root (propagate.c:139-392).  Sibling values are the bottom-up ones (not re-evaluated
+ * after the first child narrowed, as propagate.c:98,167,187,242 do): a weaker single
+ * revision with the same fixpoint, because the clause is revised again whenever one of
+ * its variables changed. */
+__device__ inline void cs_tree_revise(const cs_tables &T, int tree, cs_ctx &cx, cs_tree_scratch &S) {
+  const int base = T.tree_off[tree];
+  const int len = T.tree_off[tree + 1] - base;
+  const int4 *nd = T.tnode + base;
+  cx.revisions++;
+  cs_tree_eval(T, nd, len, cx.dom, S.val);
+
+  int sp = 0;
+#define CS_PUSH(K, W)                                                          \
+  do {                                                                         \
+    if (sp < CS_MAX_TREE_NODES) { S.node[sp] = (short)(K); S.want[sp] = (W); sp++; } \
+  } while (0)
+  CS_PUSH(len - 1, cs_value(1));
+  while (sp > 0 && !cx.fail) {
+    sp--;
+    const int k = S.node[sp];
+    const cs_val w = S.want[sp];
+    const int4 n = nd[k];
+    switch (n.x) {
+    case CS_OP_VAR:
+      cx.narrow(n.y, w);
+      break;
+    case CS_OP_CONST: /* terminal without variable: only a conflict is observable */
+      if (n.y > w.hi || n.z < w.lo) cx.fail = 1;
+      break;
+    case CS_OP_EQ: {
+      cs_val lv = S.val[n.y], rv = S.val[n.z];
+      if (cs_is_true(w)) { /* propagate.c:90-103 */
+        CS_PUSH(n.z, lv);
+        CS_PUSH(n.y, rv);
+      } else if (cs_is_false(w)) { /* propagate.c:106-136 */
+        if (cs_is_value(lv) && !cs_is_sentinel(lv.lo)) {
+          if (lv.lo == rv.lo) CS_PUSH(n.z, cs_interval(lv.lo + 1, CS_DOM_MAX));
+          else if (lv.lo == rv.hi) CS_PUSH(n.z, cs_interval(CS_DOM_MIN, lv.lo - 1));
+        }
+        if (cs_is_value(rv) && !cs_is_sentinel(rv.lo)) {
+          if (rv.lo == lv.lo) CS_PUSH(n.y, cs_interval(rv.lo + 1, CS_DOM_MAX));
+          else if (rv.lo == lv.hi) CS_PUSH(n.y, cs_interval(CS_DOM_MIN, rv.lo - 1));
+        }
+      }
+      break;
+    }
+    case CS_OP_LT: {
+      cs_val lv = S.val[n.y], rv = S.val[n.z];
+      if (cs_is_true(w)) { /* propagate.c:155-176 */
+        if (!cs_is_sentinel(lv.lo)) CS_PUSH(n.z, cs_interval(lv.lo + 1, CS_DOM_MAX));
+        if (!cs_is_sentinel(rv.hi)) CS_PUSH(n.y, cs_interval(CS_DOM_MIN, rv.hi - 1));
+      } else if (cs_is_false(w)) { /* propagate.c:179-192 */
+        CS_PUSH(n.z, cs_interval(CS_DOM_MIN, lv.hi));
+        CS_PUSH(n.y, cs_interval(rv.lo, CS_DOM_MAX));
+      }
+      break;
+    }
+    case CS_OP_NEG: /* propagate.c:211-220 */
+      CS_PUSH(n.y, cs_interval(cs_neg(w.hi), cs_neg(w.lo)));
+      break;
+    case CS_OP_ADD: { /* propagate.c:223-246 */
+      cs_val lv = S.val[n.y], rv = S.val[n.z];
+      CS_PUSH(n.z, cs_interval(cs_add(w.lo, cs_neg(lv.hi)), cs_add(w.hi, cs_neg(lv.lo))));
+      CS_PUSH(n.y, cs_interval(cs_add(w.lo, cs_neg(rv.hi)), cs_add(w.hi, cs_neg(rv.lo))));
+      break;
+    }
+    case CS_OP_MUL: { /* propagate.c:249-286 */
+      if (w.lo != CS_DOM_MIN && w.hi != CS_DOM_MIN) {
+        for (int side = 0; side < 2; side++) {
+          const int p = side == 0 ? n.z : n.y;
+          const cs_val cv = S.val[side == 0 ? n.y : n.z];
+          if (!cs_is_value(cv)) continue;
+          const int c = cv.lo;
+          if (((w.lo > 0 || w.hi < 0) && c == 0) || (cs_is_value(w) && c != 0 && (w.lo % c) != 0)) {
+            cx.fail = 1;
+            break;
+          }
+          if (c != 0) {
+            int a = w.lo / c, b = w.hi / c;
+            CS_PUSH(p, cs_interval(cs_min(a, b), cs_max(a, b)));
+          }
+        }
+      }
+      break;
+    }
+    case CS_OP_NOT: /* propagate.c:289-301 */
+      if (cs_is_true(w)) CS_PUSH(n.y, cs_value(0));
+      else if (cs_is_false(w)) CS_PUSH(n.y, cs_value(1));
+      break;
+    case CS_OP_AND: { /* propagate.c:343-358 */
+      if (cs_is_true(w)) {
+        CS_PUSH(n.z, w);
+        CS_PUSH(n.y, w);
+      } else if (cs_is_false(w)) {
+        if (cs_is_true(S.val[n.y])) CS_PUSH(n.z, w);
+        if (cs_is_true(S.val[n.z])) CS_PUSH(n.y, w);
+      }
+      break;
+    }
+    case CS_OP_OR: { /* propagate.c:361-376 */
+      if (cs_is_false(w)) {
+        CS_PUSH(n.z, w);
+        CS_PUSH(n.y, w);
+      } else if (cs_is_true(w)) {
+        if (cs_is_false(S.val[n.y])) CS_PUSH(n.z, w);
+        if (cs_is_false(S.val[n.z])) CS_PUSH(n.y, w);
+      }
+      break;
+    }
+    case CS_OP_WAND: /* propagate.c:379-392 */
+      if (cs_is_true(w))
+        for (int i = 0; i < n.z; i++) CS_PUSH(T.tkid[n.y + i], w);
+      break;
+    default:
+      break;
+    }
+  }
+#undef CS_PUSH
+}
+
+/* ---- the hot kernel: event-driven fixpoint, one wave per node ------------------- */
+
+template <bool HAS_TREE>
+__global__ __launch_bounds__(CS_BLOCK) void cs_propagate_events(cs_tables T, const cs_val *__restrict__ states_in,
+                                                                const cs_node_in *__restrict__ nodes,
+                                                                cs_val *__restrict__ states_out,
+                                                                cs_node_out *__restrict__ results, long long batch) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
+  const int lane = threadIdx.x & (CS_WAVE - 1);
+  const int wave_in_block = threadIdx.x >> 6;
+  const int n = T.n_vars, nw = T.n_words;
+  /* per-wave LDS slice: domains, then the two changed masks */
+  const size_t slice = (size_t)n * sizeof(cs_val) + 2 * (size_t)nw * sizeof(unsigned);
+  const size_t slice_al = (slice + 15) & ~(size_t)15;
+  cs_val *dom = (cs_val *)(cs_lds + wave_in_block * slice_al);
+  unsigned *mask_a = (unsigned *)(dom + n);
+  unsigned *mask_b = mask_a + nw;
+
+  const long long waves_total = (long long)gridDim.x * CS_WAVES_PER_BLOCK;
+  for (long long node = (long long)blockIdx.x * CS_WAVES_PER_BLOCK + wave_in_block; node < batch; node += waves_total) {
+    const cs_node_in nin = nodes[node];
+    const cs_val *src = states_in + (size_t)nin.parent * n;
+    for (int v = lane; v < n; v += CS_WAVE) dom[v] = src[v];
+    for (int w = lane; w < nw; w += CS_WAVE) { mask_a[w] = 0u; mask_b[w] = 0u; }
+    cs_wave_sync();
+
+    cs_ctx cx;
+    cx.dom = dom;
+    cx.mark_is_flag = 0;
+    cx.fail = 0;
+    cx.props = 0;
+    cx.revisions = 0;
+    if (nin.var >= 0) {
+      /* step_enter: bind(var, VALUE(v)) -- csolve.c:294-304; not counted in PROPS */
+      if (lane == 0) {
+        dom[nin.var] = cs_interval(nin.lo, nin.hi);
+        mask_a[nin.var >> 5] = 1u << (nin.var & 31);
+      }
+    } else {
+      for (int w = lane; w < nw; w += CS_WAVE) {
+        int rem = n - w * 32;
+        mask_a[w] = rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u);
+      }
+    }
+    cs_wave_sync();
+
+    unsigned *cur = mask_a, *nxt = mask_b;
+    int rounds = 0, failed = 0;
+    for (;;) {
+      cx.mark = nxt;
+      int any = 0;
+      for (int w = 0; w < nw && !failed; w++) {
+        unsigned bits = __builtin_amdgcn_readfirstlane(cur[w]);
+        any |= bits != 0u;
+        while (bits != 0u) {
+          const int u = w * 32 + __builtin_ctz(bits);
+          bits &= bits - 1u;
+          /* a variable whose bounds crossed through racing lo/hi updates */
+          const cs_val du = dom[u];
+          if (du.lo > du.hi) cx.fail = 1;
+          const int beg = T.adj_off[u], end = T.adj_off[u + 1];
+          for (int i = beg + lane; i < end && !cx.fail; i += CS_WAVE) {
+            const int2 e = T.adj[i];
+            if (e.x >= 0) {
+              cs_ne_revise(cx, u, e.x, e.y);
+            } else if (HAS_TREE) {
+              cs_tree_scratch S;
+              cs_tree_revise(T, ~e.x, cx, S);
+            }
+          }
+          if (__any(cx.fail)) { failed = 1; break; }
+        }
+      }
+      if (failed || !any) break;
+      rounds++;
+      cs_wave_sync();
+      for (int w = lane; w < nw; w += CS_WAVE) cur[w] = 0u;
+      cs_wave_sync();
+      unsigned *t = cur; cur = nxt; nxt = t;
+    }
+    cs_wave_sync();
+
+    /* wave totals */
+    int props = cx.props, revs = cx.revisions;
+    for (int off = 32; off > 0; off >>= 1) {
+      props += __shfl_xor(props, off);
+      revs += __shfl_xor(revs, off);
+    }
+    if (!failed) {
+      cs_val *dst = states_out + (size_t)node * n;
+      for (int v = lane; v < n; v += CS_WAVE) dst[v] = dom[v];
+    }
+    if (lane == 0) {
+      cs_node_out r;
+      r.status = failed ? -1 : 0;
+      r.props = props;
+      r.revisions = revs;
+      r.rounds = rounds;
+      results[node] = r;
+    }
+    cs_wave_sync();
+  }
+}
+
+/* ---- full sweeps (root phase): one workgroup per instance ------------------------ */
+
+__global__ __launch_bounds__(CS_BLOCK) void cs_propagate_sweeps(cs_tables T, const cs_val *__restrict__ states_in,
+                                                                cs_val *__restrict__ states_out,
+                                                                cs_node_out *__restrict__ results, int max_rounds) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
+  const int n = T.n_vars;
+  cs_val *dom = (cs_val *)cs_lds;
+  unsigned *flags = (unsigned *)(dom + n); /* [0] changed, [1] failed, [2] props, [3] revisions */
+  const int inst = blockIdx.x;
+  const cs_val *src = states_in + (size_t)inst * n;
+  for (int v = threadIdx.x; v < n; v += blockDim.x) dom[v] = src[v];
+  if (threadIdx.x < 4) flags[threadIdx.x] = 0u;
+  __syncthreads();
+
+  cs_ctx cx;
+  cx.dom = dom;
+  cx.mark = flags;
+  cx.mark_is_flag = 1;
+  cx.fail = 0;
+  cx.props = 0;
+  cx.revisions = 0;
+  int rounds = 0;
+  for (;;) {
+    for (int c = threadIdx.x; c < T.n_clauses && !cx.fail; c += blockDim.x) {
+      const int4 rec = T.clause[c];
+      if (rec.x == CS_CL_NE) {
+        cs_ne_revise(cx, rec.y, rec.z, rec.w);
+      } else if (rec.x == CS_CL_TREE) {
+        cs_tree_scratch S;
+        cs_tree_revise(T, rec.y, cx, S);
+      }
+    }
+    if (cx.fail) flags[1] = 1u;
+    __syncthreads();
+    /* an interval emptied by racing updates of lo and hi */
+    for (int v = threadIdx.x; v < n; v += blockDim.x)
+      if (dom[v].lo > dom[v].hi) flags[1] = 1u;
+    __syncthreads();
+    const unsigned changed = flags[0], failed = flags[1];
+    __syncthreads();
+    rounds++;
+    if (failed || !changed || rounds >= max_rounds) break;
+    if (threadIdx.x == 0) flags[0] = 0u;
+    __syncthreads();
+  }
+  atomicAdd(&flags[2], (unsigned)cx.props);
+  atomicAdd(&flags[3], (unsigned)cx.revisions);
+  __syncthreads();
+  cs_val *dst = states_out + (size_t)inst * n;
+  for (int v = threadIdx.x; v < n; v += blockDim.x) dst[v] = dom[v];
+  if (threadIdx.x == 0) {
+    cs_node_out r;
+    r.status = flags[1] ? -1 : 0;
+    r.props = (int)flags[2];
+    r.revisions = (int)flags[3];
+    r.rounds = rounds;
+    results[inst] = r;
+  }
+}
+
+/* ---- three-valued evaluation of the root wide-and (eval.c:233-255) ---------------- */
+
+__global__ __launch_bounds__(CS_BLOCK) void cs_eval_root(cs_tables T, const cs_val *__restrict__ states,
+                                                         int *__restrict__ truth) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
+  const int n = T.n_vars;
+  cs_val *dom = (cs_val *)cs_lds;
+  unsigned *flags = (unsigned *)(dom + n); /* [0] some clause false, [1] some clause undecided */
+  const int inst = blockIdx.x;
+  const cs_val *src = states + (size_t)inst * n;
+  for (int v = threadIdx.x; v < n; v += blockDim.x) dom[v] = src[v];
+  if (threadIdx.x < 2) flags[threadIdx.x] = 0u;
+  __syncthreads();
+  int any_false = 0, any_open = 0;
+  for (int c = threadIdx.x; c < T.n_clauses; c += blockDim.x) {
+    const int4 rec = T.clause[c];
+    cs_val v = cs_value(1);
+    if (rec.x == CS_CL_NE) {
+      /* NOT(EQ(X_a, X_b + d)); no saturation possible on this path (cs_device.h) */
+      cs_val a = dom[rec.y], b = dom[rec.z];
+      b.lo += rec.w;
+      b.hi += rec.w;
+      v = cs_ev_not(cs_ev_eq(a, b));
+    } else if (rec.x == CS_CL_TREE) {
+      cs_tree_scratch S;
+      const int base = T.tree_off[rec.y], len = T.tree_off[rec.y + 1] - base;
+      cs_tree_eval(T, T.tnode + base, len, dom, S.val);
+      v = S.val[len - 1];
+    }
+    any_false |= cs_is_false(v);
+    any_open |= !cs_is_false(v) && !cs_is_true(v);
+  }
+  if (any_false) flags[0] = 1u;
+  if (any_open) flags[1] = 1u;
+  __syncthreads();
+  if (threadIdx.x == 0) truth[inst] = flags[0] ? 0 : (flags[1] ? 2 : 1);
+}
+
+/* interval value of every clause for one state (eval_<op> per clause root) */
+__global__ __launch_bounds__(CS_BLOCK) void cs_eval_clauses(cs_tables T, const cs_val *__restrict__ state,
+                                                            cs_val *__restrict__ vals) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
+  const int n = T.n_vars;
+  cs_val *dom = (cs_val *)cs_lds;
+  for (int v = threadIdx.x; v < n; v += blockDim.x) dom[v] = state[v];
+  __syncthreads();
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < T.n_clauses; c += gridDim.x * blockDim.x) {
+    const int4 rec = T.clause[c];
+    cs_val v = cs_value(1);
+    if (rec.x == CS_CL_NE) {
+      cs_val a = dom[rec.y], b = dom[rec.z];
+      b.lo += rec.w;
+      b.hi += rec.w;
+      v = cs_ev_not(cs_ev_eq(a, b));
+    } else if (rec.x == CS_CL_TREE) {
+      cs_tree_scratch S;
+      const int base = T.tree_off[rec.y], len = T.tree_off[rec.y + 1] - base;
+      cs_tree_eval(T, T.tnode + base, len, dom, S.val);
+      v = S.val[len - 1];
+    }
+    vals[c] = v;
+  }
+}
+
+#endif /* CS_KERNELS_HIP_H */

@@ -1,0 +1,111 @@
+"""Synthetic workload generators in the csolve problem-text format.
+
+These produce the shapes BASELINE.json names: N-queens exactly as the reference's
+generator writes it (reference scripts/gen_queens.sh:3-37), sudoku-shaped alldiff
+networks scaled from 9x9 (reference examples/sudoku.txt:28-59) to 25x25, and
+schedule-style optimisation problems after reference examples/schedule.txt.
+All generators are deterministic functions of their arguments (own LCG, no `random`).
+"""
+from __future__ import annotations
+
+
+class LCG:
+    """64-bit LCG (Knuth MMIX constants); identical to the one in oracle/ref_harness.c."""
+
+    def __init__(self, seed: int):
+        self.state = seed & 0xFFFFFFFFFFFFFFFF
+
+    def next(self) -> int:
+        self.state = (self.state * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
+        return self.state >> 33
+
+    def below(self, n: int) -> int:
+        return self.next() % n
+
+    def shuffle(self, xs):
+        for i in range(len(xs) - 1, 0, -1):
+            j = self.below(i + 1)
+            xs[i], xs[j] = xs[j], xs[i]
+        return xs
+
+
+def queens(n: int, objective: str = "ANY") -> str:
+    """N-queens: three all_different lines plus 1 <= Xi <= N (gen_queens.sh:5-36)."""
+    xs = [f"X{i}" for i in range(1, n + 1)]
+    lines = [f"# N-queens problem for N={n}", f"{objective};"]
+    lines.append("all_different(" + ", ".join(xs) + ");")
+    lines.append("all_different(" + ", ".join(f"X{i}+{i}" for i in range(1, n + 1)) + ");")
+    lines.append("all_different(" + ", ".join(f"X{i}-{i}" for i in range(1, n + 1)) + ");")
+    for i in range(1, n + 1):
+        lines.append(f"1 <= X{i}; X{i} <= {n};")
+    return "\n".join(lines) + "\n"
+
+
+def _cell(r: int, c: int) -> str:
+    return f"C{r}_{c}"
+
+
+def sudoku_solution(box: int, seed: int):
+    """A valid box^2 x box^2 grid: the cyclic pattern with seeded row/column/digit shuffles."""
+    n = box * box
+    rng = LCG(seed)
+
+    def banded():
+        bands = rng.shuffle(list(range(box)))
+        out = []
+        for b in bands:
+            out.extend(b * box + r for r in rng.shuffle(list(range(box))))
+        return out
+
+    rows, cols = banded(), banded()
+    digits = rng.shuffle(list(range(1, n + 1)))
+    return [[digits[(box * (r % box) + r // box + c) % n] for c in cols] for r in rows]
+
+
+def sudoku(box: int = 3, revealed: float = 0.4, seed: int = 1, objective: str = "ANY") -> str:
+    """box^2 x box^2 sudoku: givens, then rows / columns / boxes as all_different,
+    then 1 <= cell <= n bounds (layout of examples/sudoku.txt, scaled)."""
+    n = box * box
+    grid = sudoku_solution(box, seed)
+    rng = LCG(seed ^ 0x9E3779B97F4A7C15)
+    cells = [(r, c) for r in range(n) for c in range(n)]
+    rng.shuffle(cells)
+    given = sorted(cells[: int(round(revealed * n * n))])
+    lines = [f"# sudoku {n}x{n}, {len(given)} givens, seed {seed}", f"{objective};"]
+    for r, c in given:
+        lines.append(f"{_cell(r, c)} = {grid[r][c]};")
+    for r in range(n):
+        lines.append("all_different(" + ", ".join(_cell(r, c) for c in range(n)) + ");")
+    for c in range(n):
+        lines.append("all_different(" + ", ".join(_cell(r, c) for r in range(n)) + ");")
+    for br in range(box):
+        for bc in range(box):
+            lines.append("all_different(" + ", ".join(_cell(br * box + r, bc * box + c)
+                                                      for r in range(box) for c in range(box)) + ");")
+    for r in range(n):
+        lines.append(" ".join(f"1 <= {_cell(r, c)}; {_cell(r, c)} <= {n};" for c in range(n)))
+    return "\n".join(lines) + "\n"
+
+
+def schedule(tasks: int = 16, seed: int = 1, horizon_slack: int = 3) -> str:
+    """Single-machine scheduling after examples/schedule.txt: per task release, WCET and
+    deadline, pairwise non-overlap disjunctions, MIN end."""
+    rng = LCG(seed)
+    wcet = [1 + rng.below(4) for _ in range(tasks)]
+    total = sum(wcet)
+    release = [rng.below(max(1, total // 2)) for _ in range(tasks)]
+    lines = [f"# schedule: {tasks} tasks, seed {seed}", "MIN end;"]
+    for t in range(tasks):
+        dl = total * horizon_slack
+        p = f"t{t + 1}"
+        lines.append(f"{p}_release = {release[t]};")
+        lines.append(f"{p}_release <= {p}_start;")
+        lines.append(f"{p}_end = {p}_start + {wcet[t]};")
+        lines.append(f"{p}_end <= {p}_release + {dl};")
+    for a in range(tasks):
+        for b in range(a + 1, tasks):
+            pa, pb = f"t{a + 1}", f"t{b + 1}"
+            lines.append(f"{pa}_start > {pb}_end | {pb}_start > {pa}_end;")
+    for t in range(tasks):
+        lines.append(f"end >= t{t + 1}_end;")
+    return "\n".join(lines) + "\n"

@@ -1,0 +1,179 @@
+"""Thin Python view of the C ABI: problem models and batched propagation on torch
+device buffers.  Mirrors the reference's operator vocabulary: a *model* (constraints +
+variables), *states* (one interval per variable), *nodes* (an assignment applied to a
+parent state), `propagate` (propagate_clauses for every node of a batch), `eval_root`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from ._lib import Node, Result, Val, check, load_library
+
+STATUS_FAIL = -1
+
+
+def _stream_ptr(stream) -> int:
+    if stream is None:
+        stream = torch.cuda.current_stream()
+    return int(stream.cuda_stream)
+
+
+class Model:
+    """A problem: host model + (after finalize) its device image."""
+
+    def __init__(self, handle):
+        self._h = handle
+        self.finalized = False
+
+    # ---- construction -----------------------------------------------------------------
+    @classmethod
+    def from_text(cls, text: str, weights_on: bool = True) -> "Model":
+        L = load_library()
+        h = C.c_void_p()
+        check(L.csgpu_model_from_text(text.encode(), int(weights_on), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_file(cls, path: str, weights_on: bool = True) -> "Model":
+        L = load_library()
+        h = C.c_void_p()
+        check(L.csgpu_model_from_file(path.encode(), int(weights_on), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_dump(cls, path: str) -> "Model":
+        L = load_library()
+        h = C.c_void_p()
+        check(L.csgpu_model_from_dump(path.encode(), C.byref(h)))
+        return cls(h)
+
+    def close(self):
+        if self._h:
+            load_library().csgpu_model_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- host-side queries --------------------------------------------------------------
+    @property
+    def n_vars(self) -> int:
+        return check(load_library().csgpu_model_num_vars(self._h))
+
+    @property
+    def n_clauses(self) -> int:
+        return check(load_library().csgpu_model_num_clauses(self._h))
+
+    @property
+    def objective(self) -> int:
+        return check(load_library().csgpu_model_objective(self._h))
+
+    @property
+    def objective_var(self) -> int:
+        return load_library().csgpu_model_objective_var(self._h)
+
+    def var_names(self):
+        L = load_library()
+        return [L.csgpu_model_var_name(self._h, i).decode() for i in range(self.n_vars)]
+
+    def domains(self) -> np.ndarray:
+        out = np.empty((self.n_vars, 2), dtype=np.int32)
+        check(load_library().csgpu_model_get_domains(self._h, out.ctypes.data))
+        return out
+
+    def set_domains(self, dom: np.ndarray):
+        dom = np.ascontiguousarray(dom, dtype=np.int32)
+        assert dom.shape == (self.n_vars, 2)
+        check(load_library().csgpu_model_set_domains(self._h, dom.ctypes.data))
+
+    def device_info(self) -> dict:
+        info = (C.c_int64 * 8)()
+        check(load_library().csgpu_model_device_info(self._h, info))
+        keys = ("adjacency_entries", "ne_clauses", "tree_clauses", "tree_nodes", "lds_bytes_per_node",
+                "max_list", "skipped_clauses", "max_tree")
+        return dict(zip(keys, [int(x) for x in info]))
+
+    # ---- device phases ------------------------------------------------------------------
+    def root_propagate(self) -> int:
+        """propagate(root, size) on the device; -1 = infeasible, else narrowings."""
+        st = C.c_int32()
+        check(load_library().csgpu_model_root_propagate(self._h, C.byref(st)))
+        return st.value
+
+    def build_tables(self):
+        """Host-only: clause lists + device tables in host memory (no HIP call)."""
+        check(load_library().csgpu_model_build_tables(self._h))
+        return self
+
+    def finalize(self):
+        check(load_library().csgpu_model_finalize(self._h))
+        self.finalized = True
+        return self
+
+    def root_state(self, device="cuda") -> torch.Tensor:
+        """[1, n_vars, 2] int32 tensor of the root domains."""
+        return torch.from_numpy(self.domains()).to(device).unsqueeze(0).contiguous()
+
+    def propagate(self, states_in: torch.Tensor, nodes: torch.Tensor, states_out: torch.Tensor = None,
+                  results: torch.Tensor = None, stream=None):
+        """Batched propagate_clauses.
+
+        states_in  [P, n_vars, 2] int32 (device)   parent states
+        nodes      [B, 4] int32 (device)           rows (var, lo, hi, parent_row)
+        returns (states_out [B, n_vars, 2], results [B, 4] = status, props, revisions, rounds)
+        """
+        n = self.n_vars
+        assert states_in.is_cuda and nodes.is_cuda, "device tensors required"
+        assert states_in.dtype == torch.int32 and nodes.dtype == torch.int32
+        assert states_in.is_contiguous() and nodes.is_contiguous()
+        assert states_in.shape[-2:] == (n, 2) and nodes.shape[-1] == 4
+        B = nodes.shape[0]
+        if states_out is None:
+            states_out = torch.empty((B, n, 2), dtype=torch.int32, device=nodes.device)
+        if results is None:
+            results = torch.empty((B, 4), dtype=torch.int32, device=nodes.device)
+        assert states_out.is_contiguous() and results.is_contiguous()
+        assert states_out.shape == (B, n, 2) and results.shape == (B, 4)
+        check(load_library().csgpu_propagate_batch(self._h, states_in.data_ptr(), nodes.data_ptr(),
+                                                   states_out.data_ptr(), results.data_ptr(), B,
+                                                   _stream_ptr(stream)))
+        return states_out, results
+
+    def eval_root(self, states: torch.Tensor, stream=None) -> torch.Tensor:
+        """Three-valued value of the root wide-and per state: 1 true, 0 false, 2 undecided."""
+        assert states.is_cuda and states.dtype == torch.int32 and states.is_contiguous()
+        B = states.shape[0]
+        truth = torch.empty((B,), dtype=torch.int32, device=states.device)
+        check(load_library().csgpu_eval_batch(self._h, states.data_ptr(), truth.data_ptr(), B, _stream_ptr(stream)))
+        return truth
+
+    def eval_clauses(self, state: torch.Tensor, stream=None) -> torch.Tensor:
+        """Interval value of every clause for ONE state: [n_clauses, 2]."""
+        assert state.is_cuda and state.dtype == torch.int32 and state.is_contiguous()
+        out = torch.empty((max(1, self.n_clauses), 2), dtype=torch.int32, device=state.device)
+        check(load_library().csgpu_eval_clauses(self._h, state.data_ptr(), out.data_ptr(), _stream_ptr(stream)))
+        return out[: self.n_clauses]
+
+    def propagate_one(self, state: np.ndarray, var: int, lo: int, hi: int):
+        """Single node through host buffers (the drop-in path)."""
+        state = np.ascontiguousarray(state, dtype=np.int32)
+        out = np.empty_like(state)
+        res = Result()
+        check(load_library().csgpu_propagate_one(self._h, state.ctypes.data, Node(var, lo, hi, 0),
+                                                 out.ctypes.data, C.byref(res)))
+        return res.status, res.props, out
+
+
+def solve_root(text: str, weights_on: bool = True) -> Model:
+    """Front end + root phase + finalize: parser.y's Input action up to clauses_init,
+    without the (cost-only) normalisation pass."""
+    m = Model.from_text(text, weights_on)
+    if m.root_propagate() < 0:
+        raise ValueError("INFEASIBLE PROBLEM")
+    return m.finalize()

@@ -1,0 +1,137 @@
+/* csolve_gpu.h -- C ABI of libcsolve_hip.so: the MI355X (gfx950) implementation of
+ * CSolve's constraint-propagation fixpoint.
+ *
+ * Plain C, plain pointers and sizes.  Device pointers are raw HIP device addresses
+ * (e.g. torch.Tensor.data_ptr()); `stream` is a hipStream_t passed as void* (NULL =
+ * the null stream).  Every entry returns 0 on success or a negative CSGPU_E_* code;
+ * csgpu_last_error() gives the message.  There is no CPU fallback anywhere behind
+ * this interface: without a usable HIP device the calls fail with CSGPU_E_HIP.
+ *
+ * What each entry replaces in the reference (jeuneS2/csolve, paths under src/):
+ *
+ *   csgpu_model_from_text / _from_file    the text front end up to the point where the
+ *                                         trees exist: lexer.l:36-102, parser.y:94-283
+ *   csgpu_model_root_propagate            propagate(root, size) of the Input action,
+ *                                         parser.y:59,67 -> propagate.c:474-485 (sweeps of
+ *                                         propagate_wand 379-392 over all top-level clauses)
+ *   csgpu_model_finalize                  env_generate + clauses_init, parser.y:81-83 ->
+ *                                         parser_support.c:245-257, 338-396
+ *   csgpu_propagate_batch                 check_assignment -> propagate_clauses(&var->clauses),
+ *                                         csolve.c:247-261 -> propagate.c:488-538, for a whole
+ *                                         batch of search nodes at once; each node is
+ *                                         step_enter's bind(var, VALUE(v)) (csolve.c:294-304)
+ *                                         followed by the event-driven fixpoint
+ *   csgpu_eval_batch                      update_solution's eval of the root, csolve.c:226 ->
+ *                                         eval.c:233-255 (and everything below it, eval.c:27-230)
+ *
+ * The csolve.h-named drop-in symbols (propagate, propagate_clauses, eval_*, ...) live in
+ * libcsolve_dropin.so, declared in include/csolve_dropin.h, and are thin shims over this ABI.
+ */
+#ifndef CSOLVE_GPU_H
+#define CSOLVE_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CSGPU_OK 0
+#define CSGPU_E_ARG (-1)      /* bad argument */
+#define CSGPU_E_PARSE (-2)    /* problem text rejected (message has the reference's wording) */
+#define CSGPU_E_HIP (-3)      /* HIP runtime error / no device */
+#define CSGPU_E_LIMIT (-4)    /* model exceeds a device-side limit */
+#define CSGPU_E_STATE (-5)    /* call out of order (e.g. propagate before finalize) */
+#define CSGPU_E_UNBOUNDED (-6) /* env_generate: "unbounded variable: %s" */
+
+/* closed interval, layout of reference `struct val_t` (csolve.h:43-46) */
+typedef struct csgpu_val {
+  int32_t lo, hi;
+} csgpu_val;
+
+/* one search node of a batch: take state `parent` (or the identity index), set
+ * variable `var` to [lo,hi] (a single value for step_enter, an interval for the
+ * worker split of csolve.c:121-150), propagate.  var < 0: no assignment, every
+ * variable counts as changed (full fixpoint). */
+typedef struct csgpu_node {
+  int32_t var, lo, hi, parent;
+} csgpu_node;
+
+/* per-node result.  status: -1 = PROP_ERROR (csolve.h:84), 0 = consistent.
+ * props = narrowing events (the reference's PROPS counter, propagate.c:77-78),
+ * revisions = clause revisions performed, rounds = worklist rounds. */
+typedef struct csgpu_result {
+  int32_t status, props, revisions, rounds;
+} csgpu_result;
+
+typedef struct csgpu_model csgpu_model;
+
+const char *csgpu_last_error(void);
+/* number of visible HIP devices (0 or negative error); selects `device` for this thread */
+int csgpu_device_count(void);
+int csgpu_set_device(int device);
+
+/* ---- host model ---- */
+int csgpu_model_from_text(const char *text, int weights_on, csgpu_model **out);
+int csgpu_model_from_file(const char *path, int weights_on, csgpu_model **out);
+/* a golden-model file (csolve_amd/csrc/cs_model.c) with domains and clause lists already final */
+int csgpu_model_from_dump(const char *path, csgpu_model **out);
+void csgpu_model_free(csgpu_model *m);
+
+int csgpu_model_num_vars(const csgpu_model *m);
+int csgpu_model_num_clauses(const csgpu_model *m);
+int csgpu_model_objective(const csgpu_model *m);        /* 0 ANY 1 ALL 2 MIN 3 MAX */
+int csgpu_model_objective_var(const csgpu_model *m);    /* -1 if none */
+const char *csgpu_model_var_name(const csgpu_model *m, int var);
+/* copy the current root domains (host memory, n_vars entries) */
+int csgpu_model_get_domains(const csgpu_model *m, csgpu_val *out);
+int csgpu_model_set_domains(csgpu_model *m, const csgpu_val *in);
+/* table sizes of the uploaded device image: [0] adjacency entries, [1] binary-NE clauses,
+ * [2] tree clauses, [3] tree nodes, [4] LDS bytes per node instance, [5] max list length */
+int csgpu_model_device_info(const csgpu_model *m, int64_t info[8]);
+
+/* Root phase on the device: full sweeps over every top-level clause until nothing
+ * changes.  *status = -1 if the problem is infeasible, else the number of narrowings.
+ * The model's root domains are updated in place.  (The reference stops after limit+1
+ * Gauss-Seidel sweeps, propagate.c:483; the device runs Jacobi rounds to the fixpoint,
+ * which is the same state whenever the reference reaches its fixpoint within the limit.) */
+int csgpu_model_root_propagate(csgpu_model *m, int32_t *status);
+
+/* Host-only half of finalize: env_generate + clauses_init + construction of the device
+ * tables in host memory (no HIP call).  csgpu_model_device_info works afterwards. */
+int csgpu_model_build_tables(csgpu_model *m);
+
+/* env_generate + clauses_init + upload of the search tables.  Fails with
+ * CSGPU_E_UNBOUNDED if a variable still has an infinite bound. */
+int csgpu_model_finalize(csgpu_model *m);
+
+/* ---- batched propagation (the hot path) ----
+ * d_states_in : device, [*][n_vars] csgpu_val   parent states
+ * d_nodes     : device, [batch] csgpu_node      (parent = row of d_states_in)
+ * d_states_out: device, [batch][n_vars] csgpu_val, row i = fixpoint of node i
+ *               (left unwritten when the node fails)
+ * d_results   : device, [batch] csgpu_result
+ * Asynchronous on `stream`; no host synchronisation inside. */
+int csgpu_propagate_batch(const csgpu_model *m, const csgpu_val *d_states_in, const csgpu_node *d_nodes,
+                          csgpu_val *d_states_out, csgpu_result *d_results, int64_t batch, void *stream);
+
+/* Three-valued evaluation of the root wide-and for a batch of states:
+ * d_truth[i] = 1 (all clauses true), 0 (some clause false), 2 (undecided). */
+int csgpu_eval_batch(const csgpu_model *m, const csgpu_val *d_states, int32_t *d_truth, int64_t batch,
+                     void *stream);
+
+/* Interval value of every clause (top-level constraint) for ONE state: the eval_<op>
+ * entry points of the reference (eval.c:27-255) applied to each clause root.
+ * d_vals: device, [n_clauses] csgpu_val. */
+int csgpu_eval_clauses(const csgpu_model *m, const csgpu_val *d_state, csgpu_val *d_vals, void *stream);
+
+/* Convenience for single nodes with host buffers (used by the drop-in shim):
+ * uploads `state` (n_vars), runs one node, downloads the result.  Synchronous. */
+int csgpu_propagate_one(const csgpu_model *m, const csgpu_val *state, csgpu_node node, csgpu_val *state_out,
+                        csgpu_result *result);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

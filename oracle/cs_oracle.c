@@ -553,6 +553,22 @@ int64_t cso_instance(cso *o, const cs_val *dom_in, int32_t var, cs_val val, cs_v
   return var >= 0 ? (int64_t)o->props : (int64_t)r;
 }
 
+uint64_t cso_instances(cso *o, const cs_val *states_in, const int32_t *nodes, int64_t count, cs_val *states_out,
+                       int64_t *status) {
+  const size_t n = (size_t)o->m->n_vars;
+  uint64_t binds = 0;
+  for (int64_t i = 0; i < count; i++) {
+    const int32_t *nd = &nodes[4 * i];
+    cs_val v;
+    v.lo = nd[1];
+    v.hi = nd[2];
+    int64_t st = cso_instance(o, states_in + (size_t)nd[3] * n, nd[0], v, states_out ? states_out + (size_t)i * n : NULL);
+    if (status) status[i] = st;
+    binds += o->props;
+  }
+  return binds;
+}
+
 /* ---- search driver (csolve.c) ----------------------------------------------- */
 
 typedef struct {

@@ -79,6 +79,12 @@ void cso_log_clear(cso *o);
  * dom_in) receives the domains (meaningful only on success). */
 int64_t cso_instance(cso *o, const cs_val *dom_in, int32_t var, cs_val val, cs_val *dom_out);
 
+/* cso_instance over a batch with single-value assignments.  states_in holds the parent
+ * states ([*][n_vars]); nodes[i] = {var, lo, hi, parent_row}; status[i] = CSO_ERROR or PROPS;
+ * states_out row i (may be NULL).  Returns the total number of binds, failed nodes included. */
+uint64_t cso_instances(cso *o, const cs_val *states_in, const int32_t *nodes, int64_t count, cs_val *states_out,
+                       int64_t *status);
+
 /* ---- search driver (csolve.c:398-476) ---- */
 typedef struct cso_options {
   int prefer_failing;        /* -f, default 1 */

@@ -103,6 +103,8 @@ def lib():
         L.cso_log_clear.argtypes = [vp]
         L.cso_instance.restype = i64
         L.cso_instance.argtypes = [vp, vp, i32, Val, vp]
+        L.cso_instances.restype = u64
+        L.cso_instances.argtypes = [vp, vp, vp, i64, vp, vp]
         L.cso_default_options.argtypes = [C.POINTER(Options)]
         L.cso_solve.argtypes = [vp, C.POINTER(Options), C.POINTER(Result)]
         L.cso_result_free.argtypes = [C.POINTER(Result)]
@@ -304,6 +306,18 @@ class Oracle:
                                        Val(int(val[i]), int(val[i])), out.ctypes.data + i * stride)
         return status, out
 
+    def instances_nodes(self, states_in: np.ndarray, nodes: np.ndarray, want_states: bool = True):
+        """Same batch interface as the device path: states_in [P,n,2], nodes [B,4] rows
+        (var, lo, hi, parent_row).  -> (status[B], states_out[B,n,2] or None, total binds)"""
+        states_in = np.ascontiguousarray(states_in, dtype=np.int32)
+        nodes = np.ascontiguousarray(nodes, dtype=np.int32)
+        B = nodes.shape[0]
+        out = np.empty((B,) + states_in.shape[1:], dtype=np.int32) if want_states else None
+        status = np.empty(B, dtype=np.int64)
+        binds = lib().cso_instances(self.ptr, states_in.ctypes.data, nodes.ctypes.data, B,
+                                    out.ctypes.data if want_states else None, status.ctypes.data)
+        return status, out, int(binds)
+
     def solve(self, prefer_failing=True, restart_frequency=100, order=0, max_calls=0, max_solutions=0):
         opt = Options()
         lib().cso_default_options(C.byref(opt))
@@ -327,7 +341,12 @@ class Oracle:
 def read_walk(path: str):
     """Read a walk file written by oracle/_ref/csolve_ref walk.
     -> dict(n_vars, var[B], value[B], status[B], before[B,n,2], after[B,n,2])"""
-    raw = np.fromfile(path, dtype=np.int32)
+    if path.endswith(".gz"):
+        import gzip
+        with gzip.open(path, "rb") as f:
+            raw = np.frombuffer(f.read(), dtype=np.int32)
+    else:
+        raw = np.fromfile(path, dtype=np.int32)
     if raw[0] != 0x4B575343 or raw[1] != 1:
         raise ValueError(path + ": not a walk file")
     n, B = int(raw[2]), int(raw[3])

@@ -1,0 +1,197 @@
+"""GPU parity: the HIP path (through the C ABI) against the reference's golden walks,
+against the CPU oracle on the same seeded inputs, and through size-independent
+properties at the BASELINE sizes.  Bit-exact: integer interval domains."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+NE_ONLY = {"queens4", "queens8", "queens16", "queens64", "sudoku9_s7", "ref_sudoku"}
+WALKS_WITH_MODEL = sorted(os.path.basename(p)[:-8] for p in glob.glob(golden("walks", "*.walk.gz"))
+                          if os.path.exists(golden("models", os.path.basename(p)[:-8] + ".model")))
+
+
+def _gpu_walk(model, walk):
+    before = torch.from_numpy(walk["before"]).cuda().contiguous()
+    B = before.shape[0]
+    nodes = np.stack([walk["var"], walk["value"], walk["value"], np.arange(B, dtype=np.int32)], 1).astype(np.int32)
+    out, res = model.propagate(before, torch.from_numpy(nodes).cuda())
+    torch.cuda.synchronize()
+    return out.cpu().numpy(), res.cpu().numpy()
+
+
+@pytest.mark.parametrize("name", WALKS_WITH_MODEL)
+def test_reference_walks_on_reference_model(name):
+    """Every golden node instance (recorded from the compiled reference): same verdict, same
+    fixpoint domains; on pure != networks also the same PROPS count."""
+    from csolve_amd.solver import Model
+    from oracle.cs_oracle import read_walk
+    walk = read_walk(golden("walks", name + ".walk.gz"))
+    model = Model.from_dump(golden("models", name + ".model")).finalize()
+    out, res = _gpu_walk(model, walk)
+    fail_ref = walk["status"] < 0
+    assert ((res[:, 0] < 0) == fail_ref).all()
+    ok = ~fail_ref
+    assert (out[ok] == walk["after"][ok]).all()
+    if name in NE_ONLY:
+        assert (res[ok, 1] == walk["status"][ok]).all()
+
+
+@pytest.mark.parametrize("name", sorted(os.path.basename(p)[:-8] for p in glob.glob(golden("walks", "*.walk.gz"))))
+def test_reference_walks_through_own_front_end(name):
+    """Same instances, but the model is built from the problem TEXT by the product's own
+    front end and root phase (device), not loaded from the reference's dump."""
+    from csolve_amd.solver import solve_root
+    from oracle.cs_oracle import read_walk
+    walk = read_walk(golden("walks", name + ".walk.gz"))
+    model = solve_root(open(golden("problems", name + ".txt")).read())
+    assert model.n_vars == walk["n_vars"]
+    out, res = _gpu_walk(model, walk)
+    fail_ref = walk["status"] < 0
+    assert ((res[:, 0] < 0) == fail_ref).all()
+    ok = ~fail_ref
+    assert (out[ok] == walk["after"][ok]).all()
+
+
+@pytest.mark.parametrize("name", ["queens8", "queens64", "ref_sudoku", "ref_schedule", "ref_wcet", "schedule6_s1"])
+def test_root_phase_matches_reference_dump(name):
+    """parse + device root sweeps reach the root domains the reference reached."""
+    from csolve_amd.solver import Model, solve_root
+    ref = Model.from_dump(golden("models", name + ".model"))
+    mine = solve_root(open(golden("problems", name + ".txt")).read())
+    assert mine.var_names() == ref.var_names()
+    assert (mine.domains() == ref.domains()).all()
+
+
+def test_infeasible_root():
+    from csolve_amd.solver import Model
+    m = Model.from_text("ANY; x = 1; x = 2;")
+    assert m.root_propagate() == -1
+    m = Model.from_text("ANY; 1 = 2;")
+    assert m.root_propagate() == -1
+    m = Model.from_text("ANY; x < y; y < x; 0 <= x; x <= 5; 0 <= y; y <= 5;")
+    assert m.root_propagate() == -1
+
+
+def test_unbounded_variable_is_reported():
+    from csolve_amd import CsolveError
+    from csolve_amd.solver import Model
+    m = Model.from_text("ANY; x < y; 0 <= x;")
+    assert m.root_propagate() >= 0
+    with pytest.raises(CsolveError, match="unbounded variable: "):
+        m.finalize()
+
+
+def _random_nodes(rng, states, count):
+    """pick open variables and values inside their current interval"""
+    B, n, _ = states.shape
+    nodes = np.zeros((count, 4), dtype=np.int32)
+    for i in range(count):
+        p = rng.integers(B)
+        open_vars = np.nonzero(states[p, :, 0] < states[p, :, 1])[0]
+        v = open_vars[rng.integers(len(open_vars))] if len(open_vars) else rng.integers(n)
+        val = rng.integers(states[p, v, 0], states[p, v, 1] + 1)
+        nodes[i] = (v, val, val, p)
+    return nodes
+
+
+@pytest.mark.parametrize("kind,size", [("queens", 64), ("queens", 128), ("sudoku", 5), ("schedule", 16)])
+def test_batch_vs_oracle_and_properties(kind, size):
+    """Seeded multi-level batches at the BASELINE sizes: a sample is checked against the oracle
+    bit for bit; the whole batch is checked through properties -- the output is contained in the
+    input, is a fixpoint (re-propagating it with every variable marked changed narrows nothing),
+    and the verdict does not depend on how the batch is split."""
+    from csolve_amd import problems
+    from csolve_amd.solver import solve_root
+    from oracle.cs_oracle import Model as OModel, Oracle
+    text = {"queens": lambda: problems.queens(size), "sudoku": lambda: problems.sudoku(size, 0.4, 1),
+            "schedule": lambda: problems.schedule(size, 1)}[kind]()
+    model = solve_root(text)
+    n = model.n_vars
+    omodel = OModel.parse(text)
+    omodel.set_domains(model.domains())
+    omodel.index()
+    orc = Oracle(omodel)
+
+    rng = np.random.default_rng(2024)
+    states = model.domains()[None].copy()
+    for level in range(4):
+        count = 4096 if level == 3 else 512
+        nodes = _random_nodes(rng, states, count)
+        d_states = torch.from_numpy(states).cuda()
+        d_nodes = torch.from_numpy(nodes).cuda()
+        out, res = model.propagate(d_states, d_nodes)
+        torch.cuda.synchronize()
+        out_h, res_h = out.cpu().numpy(), res.cpu().numpy()
+        ok = res_h[:, 0] >= 0
+        # oracle on a sample
+        sample = rng.choice(count, size=min(count, 192), replace=False)
+        st, exp = orc.instances(states[nodes[sample, 3]], nodes[sample, 0], nodes[sample, 1])
+        assert ((st < 0) == ~ok[sample]).all()
+        good = sample[st >= 0]
+        assert (out_h[good] == exp[st >= 0]).all()
+        if kind != "schedule":
+            assert (res_h[good, 1] == st[st >= 0]).all()
+        # contained in the parent state with the assignment applied
+        parent = states[nodes[:, 3]]
+        assert (out_h[ok, :, 0] >= parent[ok, :, 0]).all() and (out_h[ok, :, 1] <= parent[ok, :, 1]).all()
+        assert (out_h[ok, :, 0] <= out_h[ok, :, 1]).all()
+        idx = np.nonzero(ok)[0]
+        assert (out_h[idx, nodes[idx, 0], 0] == nodes[idx, 1]).all()
+        # fixpoint: full re-propagation changes nothing
+        again_nodes = np.stack([np.full(len(idx), -1), np.zeros(len(idx)), np.zeros(len(idx)),
+                                np.arange(len(idx))], 1).astype(np.int32)
+        sub = out[torch.from_numpy(idx).cuda()].contiguous()
+        out2, res2 = model.propagate(sub, torch.from_numpy(again_nodes).cuda())
+        torch.cuda.synchronize()
+        assert (res2[:, 0] == 0).all() and (res2[:, 1] == 0).all()
+        assert torch.equal(out2, sub)
+        # splitting the batch does not change anything
+        half = count // 2
+        o1, r1 = model.propagate(d_states, d_nodes[:half].contiguous())
+        o2, r2 = model.propagate(d_states, d_nodes[half:].contiguous())
+        torch.cuda.synchronize()
+        assert torch.equal(torch.cat([r1, r2])[:, 0], res[:, 0])
+        okt = torch.from_numpy(ok).cuda()
+        assert torch.equal(torch.cat([o1, o2])[okt], out[okt])
+        states = out_h[ok][:256]
+        if len(states) == 0:
+            break
+
+
+def test_eval_root_on_solutions():
+    """update_solution's check: the root evaluates to true on a solution, false on a
+    violated assignment, undecided on an open state."""
+    import json
+    from csolve_amd.solver import solve_root
+    stats = json.load(open(golden("solve_stats.json")))
+    rec = next(r for r in stats if r["problem"] == "queens8" and not r["flags"])
+    model = solve_root(open(golden("problems", "queens8.txt")).read())
+    names = model.var_names()
+    sol = np.array([[rec["last_solution"][k]] * 2 for k in names], dtype=np.int32)
+    bad = sol.copy()
+    bad[0] = bad[1]
+    states = np.stack([sol, bad, model.domains()])
+    truth = model.eval_root(torch.from_numpy(states).cuda()).cpu().numpy()
+    assert truth.tolist() == [1, 0, 2]
+
+
+def test_propagate_one_host_path():
+    from csolve_amd.solver import Model
+    from oracle.cs_oracle import read_walk
+    walk = read_walk(golden("walks", "queens8.walk.gz"))
+    model = Model.from_dump(golden("models", "queens8.model")).finalize()
+    for i in range(40):
+        st, props, out = model.propagate_one(walk["before"][i], int(walk["var"][i]), int(walk["value"][i]),
+                                             int(walk["value"][i]))
+        if walk["status"][i] < 0:
+            assert st == -1
+        else:
+            assert st == 0 and props == walk["status"][i] and (out == walk["after"][i]).all()

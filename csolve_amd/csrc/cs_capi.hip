@@ -215,7 +215,7 @@ extern "C" int csgpu_model_root_propagate(csgpu_model *m, int32_t *status) {
   if (h->root < 0) return set_err(CSGPU_E_STATE, "model has no root");
   if (!m->from_dump && cs_model_index(h) != 0) return set_err(CSGPU_E_ARG, "%s", h->err);
   char err[200];
-  cs_dev_image *g = cs_dev_image_build(h, 0, err, sizeof err);
+  cs_dev_image *g = cs_dev_image_build(h, 0, NULL, err, sizeof err);
   if (g == NULL) return set_err(CSGPU_E_LIMIT, "%s", err);
 
   dev_tables_owner own;
@@ -261,7 +261,7 @@ extern "C" int csgpu_model_build_tables(csgpu_model *m) {
   m->img = NULL;
   m->finalized = 0;
   char err[200];
-  m->img = cs_dev_image_build(h, 1, err, sizeof err);
+  m->img = cs_dev_image_build(h, 1, NULL, err, sizeof err);
   if (m->img == NULL) return set_err(CSGPU_E_LIMIT, "%s", err);
   const size_t slice = (size_t)h->n_vars * sizeof(cs_val) + 2 * (size_t)((h->n_vars + 31) / 32) * sizeof(unsigned);
   m->slice = (slice + 15) & ~(size_t)15;
@@ -277,6 +277,45 @@ extern "C" int csgpu_model_finalize(csgpu_model *m) {
 
   dev_tables_owner own;
   int rc = upload_image(m->img, &own, &m->tab);
+  if (rc == CSGPU_OK && h->n_clauses > 0) {
+    /* Clauses that already evaluate to true in the root state are entailed for the whole
+     * search: evaluate every clause once on the device and drop those from the tables. */
+    cs_val *d_state = NULL, *d_vals = NULL;
+    const size_t lds0 = (size_t)h->n_vars * sizeof(cs_val) + 16;
+    cs_val *vals = (cs_val *)malloc((size_t)h->n_clauses * sizeof(cs_val));
+    unsigned char *entailed = (unsigned char *)calloc((size_t)h->n_clauses, 1);
+    hipError_t e = hipSuccess;
+    rc = lds_limit(lds0, (const void *)cs_eval_clauses);
+    if (rc == CSGPU_OK &&
+        ((e = hipMalloc((void **)&d_state, (size_t)(h->n_vars ? h->n_vars : 1) * sizeof(cs_val))) != hipSuccess ||
+         (e = hipMalloc((void **)&d_vals, (size_t)h->n_clauses * sizeof(cs_val))) != hipSuccess ||
+         (e = hipMemcpy(d_state, h->dom, (size_t)h->n_vars * sizeof(cs_val), hipMemcpyHostToDevice)) != hipSuccess))
+      rc = set_err(CSGPU_E_HIP, "finalize: %s", hipGetErrorString(e));
+    if (rc == CSGPU_OK) {
+      unsigned blocks = (unsigned)((h->n_clauses + CS_BLOCK - 1) / CS_BLOCK);
+      if (blocks > 1024u) blocks = 1024u;
+      hipLaunchKernelGGL(cs_eval_clauses, dim3(blocks), dim3(CS_BLOCK), lds0, 0, m->tab, d_state, d_vals);
+      if ((e = hipGetLastError()) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess ||
+          (e = hipMemcpy(vals, d_vals, (size_t)h->n_clauses * sizeof(cs_val), hipMemcpyDeviceToHost)) != hipSuccess)
+        rc = set_err(CSGPU_E_HIP, "finalize: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(d_state); (void)hipFree(d_vals);
+    if (rc == CSGPU_OK) {
+      int any = 0;
+      for (int32_t c = 0; c < h->n_clauses; c++)
+        if (m->img->clause[4 * c] != CS_CL_SKIP && cs_is_true(vals[c])) { entailed[c] = 1; any = 1; }
+      if (any) {
+        free_tables(&own);
+        memset(&own, 0, sizeof own);
+        cs_dev_image_free(m->img);
+        char err2[200];
+        m->img = cs_dev_image_build(h, 1, entailed, err2, sizeof err2);
+        if (m->img == NULL) rc = set_err(CSGPU_E_LIMIT, "%s", err2);
+        else rc = upload_image(m->img, &own, &m->tab);
+      }
+    }
+    free(vals); free(entailed);
+  }
   m->d_adj_off = own.adj_off; m->d_adj = own.adj; m->d_clause = own.clause;
   m->d_tree_off = own.tree_off; m->d_tnode = own.tnode; m->d_tkid = own.tkid;
   if (rc != CSGPU_OK) return rc;

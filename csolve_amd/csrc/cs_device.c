@@ -113,7 +113,8 @@ void cs_dev_image_free(cs_dev_image *g) {
   free(g);
 }
 
-cs_dev_image *cs_dev_image_build(const cs_model *m, int with_lists, char *err, size_t errlen) {
+cs_dev_image *cs_dev_image_build(const cs_model *m, int with_lists, const unsigned char *entailed, char *err,
+                                 size_t errlen) {
   if (m->clause_node == NULL || (with_lists && m->list_off == NULL)) {
     if (err) snprintf(err, errlen, "model has no clause index");
     return NULL;
@@ -135,7 +136,7 @@ cs_dev_image *cs_dev_image_build(const cs_model *m, int with_lists, char *err, s
     const cs_node *rn = &m->nodes[root];
     int32_t *rec = &g->clause[4 * c];
     int32_t a, b, d;
-    if (rn->op == CS_OP_CONST && rn->a <= 1 && rn->b >= 1 && rn->a == rn->b) {
+    if ((entailed != NULL && entailed[c]) || (rn->op == CS_OP_CONST && rn->a == 1 && rn->b == 1)) {
       rec[0] = CS_CL_SKIP;
       g->n_skip++;
     } else if (match_ne(m, root, &a, &b, &d)) {

@@ -61,8 +61,14 @@ typedef struct cs_dev_image {
   int32_t *tkid;        /* [n_tkids] */
 } cs_dev_image;
 
-/* with_lists = 0: clause-centric view only (root phase, lists not needed) */
-cs_dev_image *cs_dev_image_build(const cs_model *m, int with_lists, char *err, size_t errlen);
+/* with_lists = 0: clause-centric view only (root phase, lists not needed).
+ * entailed (may be NULL): one byte per clause; a non-zero byte marks a clause whose root
+ * evaluates to true in the root state.  Domains only shrink below the root, so such a clause
+ * can never narrow or fail again; it is stored as CS_CL_SKIP and left out of the adjacency.
+ * (The reference reaches the same effect by folding the clause to the constant 1 in its
+ * root normalisation pass, reference src/normalize.c:67-75 via parser.y:66.) */
+cs_dev_image *cs_dev_image_build(const cs_model *m, int with_lists, const unsigned char *entailed, char *err,
+                                 size_t errlen);
 void cs_dev_image_free(cs_dev_image *img);
 
 #ifdef __cplusplus

@@ -47,7 +47,7 @@ SOLVES = [
     ("queens64", []), ("queens8_all", DET), ("queens8_all", []), ("queens10_all", ["-c", "false"]),
     ("sudoku9_s7", []), ("ref_sudoku", []), ("ref_sudoku", DET),
     ("ref_schedule", ["-c", "false"]),
-    ("schedule6_s1", ["-c", "false"]),
+    ("schedule6_s1", ["-c", "false", "-f", "false"]),
     ("queens8", ["-c", "false", "-o", "smallest-domain"]), ("queens16", ["-c", "false", "-o", "largest-value", "-r", "0"]),
 ]
 
@@ -79,7 +79,8 @@ def main():
         if walks:
             wpath = os.path.join(HERE, "walks", name + ".walk")
             print(name, run(["walk", path, "12345", str(walks), wpath, "-c", "false"]).strip())
-            with open(wpath, "rb") as fi, gzip.open(wpath + ".gz", "wb", compresslevel=9) as fo:
+            with open(wpath, "rb") as fi, open(wpath + ".gz", "wb") as raw, \
+                    gzip.GzipFile(filename="", mode="wb", compresslevel=9, fileobj=raw, mtime=0) as fo:
                 shutil.copyfileobj(fi, fo)
             os.remove(wpath)
 

@@ -1,0 +1,141 @@
+"""CPU tests of the host side: the C ABI library loads and exports what include/csolve_gpu.h
+declares, the front end and the clause index replay the reference (checked against the
+reference's own post-root dumps), the device tables classify clauses as documented.
+No compute call is made here (there is no GPU in this tier)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import golden
+from oracle.cs_oracle import Model as OModel, Oracle, lib as olib
+
+MODELS = ["queens4", "queens8", "queens16", "queens64", "ref_sudoku", "sudoku9_s7", "ref_schedule", "ref_wcet",
+          "schedule6_s1"]
+
+
+def test_library_exports_every_declared_symbol():
+    from csolve_amd import _lib
+    L = _lib.load_library()
+    names = _lib.declared_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(L, n), n
+
+
+def test_no_device_means_loud_failure():
+    """Without a HIP device the compute entry points fail with the library's error; nothing
+    falls back to a CPU implementation."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from csolve_amd import CsolveError
+    from csolve_amd.solver import Model
+    m = Model.from_text(open(golden("problems", "queens8.txt")).read())
+    with pytest.raises(CsolveError, match="hip|HIP|device"):
+        m.root_propagate()
+    d = Model.from_dump(golden("models", "queens8.model"))
+    with pytest.raises(CsolveError):
+        d.finalize()
+
+
+def test_missing_library_is_an_import_error(monkeypatch, tmp_path):
+    from csolve_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libcsolve_hip.so"))
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        _lib.load_library()
+
+
+@pytest.mark.parametrize("text,msg", [
+    ("ANY; x = ;", "syntax error"),
+    ("x = 1;", "expecting ANY or ALL or MIN or MAX"),
+    ("ANY; x = 1 ? 2;", "invalid input `?' in line 1"),
+    ("ANY;\n\nx < ;", "in line 3"),
+    ("ANY; all_different(a, b;", "expecting ')'"),
+])
+def test_parse_errors(text, msg):
+    from csolve_amd import CsolveError
+    from csolve_amd.solver import Model
+    with pytest.raises(CsolveError) as e:
+        Model.from_text(text)
+    assert e.value.code == -2 and msg in str(e.value)
+
+
+def test_number_and_identifier_tokens():
+    """lexer.l:36-102: binary, octal, decimal, hex literals; identifiers with _ @ $; comments."""
+    from csolve_amd.solver import Model
+    m = Model.from_text("ANY; # comment\n _a@$1 = 0b101; b = 017; c = 0x1F; d = 42; e = 0;\n")
+    assert m.var_names() == ["_a@$1", "b", "c", "d", "e"]
+    om = OModel.parse("ANY; _a@$1 = 0b101; b = 017; c = 0x1F; d = 42; e = 0;")
+    o = Oracle(om)
+    o.set_root_phase(True)
+    assert o.propagate(om.root, om.n_vars) >= 0
+    assert o.domains()[:, 0].tolist() == [5, 15, 31, 42, 0]
+
+
+@pytest.mark.parametrize("name", MODELS)
+def test_front_end_matches_reference_dump(name):
+    """Variables (names, order), initial-order weights, root domains: our parser + the oracle's
+    root sweeps against what the compiled reference dumped after its own root phase."""
+    ref = OModel.load(golden("models", name + ".model"))
+    mine = OModel.parse(open(golden("problems", name + ".txt")).read())
+    assert mine.names() == ref.names()
+    assert [mine.view.prio[i] for i in range(mine.n_vars)] == [ref.view.prio[i] for i in range(ref.n_vars)]
+    assert mine.view.objective == ref.view.objective and mine.view.obj_var == ref.view.obj_var
+    o = Oracle(mine)
+    o.set_root_phase(True)
+    assert o.propagate(mine.root, mine.n_vars) >= 0
+    assert (o.domains() == ref.domains()).all()
+
+
+@pytest.mark.parametrize("name", MODELS)
+def test_clause_index_replays_clauses_init(name):
+    """cs_model_index() on the reference's dumped trees reproduces the reference's own
+    per-variable clause lists (parser_support.c:338-396), entry for entry."""
+    ref = OModel.load(golden("models", name + ".model"))
+    n = ref.n_vars
+    want_off = [ref.view.list_off[i] for i in range(n + 1)]
+    want = [ref.view.list[i] for i in range(want_off[n])]
+    want_nodes = [ref.view.clause_node[i] for i in range(ref.n_clauses)]
+    ref.index()
+    assert [ref.view.list_off[i] for i in range(n + 1)] == want_off
+    assert [ref.view.list[i] for i in range(want_off[n])] == want
+    assert [ref.view.clause_node[i] for i in range(ref.n_clauses)] == want_nodes
+
+
+def test_model_file_round_trip(tmp_path):
+    ref = OModel.load(golden("models", "ref_wcet.model"))
+    p = str(tmp_path / "x.model")
+    ref.save(p)
+    again = OModel.load(p)
+    ok, why = ref.equal(again)
+    assert ok, why
+
+
+def test_device_tables_classification():
+    """Binary != clauses take the 16-byte fast path; everything else is a tree; constant-true
+    elements are skipped (queens-64 = 6,048 clauses, list 189, CSR 12,096)."""
+    from csolve_amd.solver import Model
+    q = Model.from_dump(golden("models", "queens64.model")).build_tables().device_info()
+    assert q["ne_clauses"] == 6048 and q["tree_clauses"] == 0 and q["adjacency_entries"] == 12096
+    assert q["max_list"] == 189 and q["lds_bytes_per_node"] == 64 * 8 + 16
+    s = Model.from_dump(golden("models", "ref_sudoku.model")).build_tables().device_info()
+    assert s["ne_clauses"] + s["skipped_clauses"] == 1158 and s["adjacency_entries"] == 1256 and s["max_list"] == 24
+    w = Model.from_dump(golden("models", "ref_wcet.model")).build_tables().device_info()
+    assert w["ne_clauses"] == 0 and w["tree_clauses"] == 15 and w["max_tree"] == 53
+
+
+def test_generators_are_deterministic_and_reference_shaped():
+    from csolve_amd import problems
+    assert problems.queens(8) == open(golden("problems", "queens8.txt")).read()
+    assert problems.sudoku(3, 0.4, 7) == open(golden("problems", "sudoku9_s7.txt")).read()
+    assert problems.schedule(6, 1) == open(golden("problems", "schedule6_s1.txt")).read()
+    grid = problems.sudoku_solution(5, 1)
+    for r in range(25):
+        assert sorted(grid[r]) == list(range(1, 26))
+        assert sorted(grid[i][r] for i in range(25)) == list(range(1, 26))
+    for br in range(5):
+        for bc in range(5):
+            assert sorted(grid[br * 5 + i][bc * 5 + j] for i in range(5) for j in range(5)) == list(range(1, 26))

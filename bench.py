@@ -77,6 +77,82 @@ def make_instances(model, count, seed, walks=8192):
     return torch.cat(states).contiguous(), torch.cat(nodes).contiguous()
 
 
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "csolve_ref")
+
+
+def cpu_baseline(args, text, model, states_in, nodes, states_out, res_h):
+    """The reference CPU propagator on one host core over a bounded sample of the SAME instances,
+    used at the same time as the checker of the device results on that sample.
+    kind "reference": the compiled reference itself (oracle/_ref/csolve_ref, built from the
+    reference's own sources in the authoring container and shipped as a binary);
+    kind "port": the oracle restatement, when that binary is not there."""
+    import subprocess
+    import tempfile
+    n = model.n_vars
+    B = nodes.shape[0]
+    si = states_in.cpu().numpy()
+    nd = nodes.cpu().numpy()
+    so = states_out.cpu().numpy()
+
+    def check(sel, status, after):
+        fail = status < 0
+        assert (fail == (res_h[sel, 0] < 0)).all(), "device verdicts differ from the CPU reference"
+        assert (so[sel][~fail] == after[~fail]).all(), "device fixpoints differ from the CPU reference"
+        assert (res_h[sel, 1][~fail] == status[~fail]).all(), "device PROPS differ from the CPU reference"
+
+    if os.path.exists(REF_BIN):
+        # pilot chunk to size the sample for the time budget, then one timed run
+        with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+            prob = os.path.join(tmp, "problem.txt")
+            open(prob, "w").write(text)
+
+            def run(count):
+                rec = np.concatenate([nd[:count, 0:2], si[nd[:count, 3]].reshape(count, 2 * n)], 1).astype(np.int32)
+                fin, fout = os.path.join(tmp, "inst.in"), os.path.join(tmp, "res.out")
+                with open(fin, "wb") as f:
+                    np.array([0x4E495343, n, count], dtype=np.int32).tofile(f)
+                    rec.tofile(f)
+                p = subprocess.run([REF_BIN, "bench", prob, fin, fout, "-c", "false"], capture_output=True, text=True)
+                if p.returncode != 0:
+                    raise RuntimeError("csolve_ref bench failed: " + p.stderr)
+                stats = json.loads(p.stdout.split("@BENCH ", 1)[1])
+                raw = np.fromfile(fout, dtype=np.int32)[3:].reshape(count, 1 + 2 * n)
+                return stats, raw[:, 0].astype(np.int64), raw[:, 1:].reshape(count, n, 2)
+
+            pilot = min(B, 4096)
+            stats, st, after = run(pilot)
+            count = int(min(B, max(pilot, pilot * args.cpu_seconds / max(stats["seconds"], 1e-6))))
+            if count > pilot:
+                stats, st, after = run(count)
+            check(slice(0, count), st, after)
+            return {"value": stats["binds"] / stats["seconds"], "unit": "propagations/s", "cores": 1,
+                    "kind": "reference", "nodes_per_s": count / stats["seconds"],
+                    "sample": f"first {count} of the {B} instances of this run through the compiled reference's "
+                              f"propagate_clauses() (gcc -O3, conflict learning off), {stats['seconds']:.1f} s on one "
+                              f"host core; device verdicts, fixpoints and PROPS re-checked against it bit for bit"}
+
+    from oracle.cs_oracle import Model as OModel, Oracle
+    omodel = OModel.parse(text)
+    omodel.set_domains(model.domains())
+    omodel.index()
+    orc = Oracle(omodel)
+    chunk, done, binds, spent = 2048, 0, 0, 0.0
+    while done < B and spent < args.cpu_seconds:
+        sel = slice(done, min(B, done + chunk))
+        nd_c = nd[sel].copy()
+        nd_c[:, 3] -= done
+        c0 = time.perf_counter()
+        st, exp, b = orc.instances_nodes(si[sel], nd_c)
+        spent += time.perf_counter() - c0
+        binds += b
+        check(sel, st, exp)
+        done += nd_c.shape[0]
+    return {"value": binds / spent, "unit": "propagations/s", "cores": 1, "kind": "port",
+            "nodes_per_s": done / spent,
+            "sample": f"first {done} of the {B} instances of this run through the oracle restatement, {spent:.1f} s "
+                      f"on one host core; device results re-checked against it bit for bit"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -173,33 +249,7 @@ def main():
     }
 
     if rank == 0 and world == 1 and not args.no_cpu:
-        from oracle.cs_oracle import Model as OModel, Oracle
-        omodel = OModel.parse(text)
-        omodel.set_domains(model.domains())
-        omodel.index()
-        orc = Oracle(omodel)
-        si = states_in.cpu().numpy()
-        nd = nodes.cpu().numpy()
-        so = states_out.cpu().numpy()
-        chunk, done, binds, spent = 2048, 0, 0, 0.0
-        while done < B and spent < args.cpu_seconds:
-            sel = slice(done, min(B, done + chunk))
-            nd_c = nd[sel].copy()
-            nd_c[:, 3] -= done
-            c0 = time.perf_counter()
-            st, exp, b = orc.instances_nodes(si[sel], nd_c)
-            spent += time.perf_counter() - c0
-            binds += b
-            # the oracle as checker: verdicts, fixpoints and PROPS of the device results
-            fail = st < 0
-            assert (fail == (res_h[sel, 0] < 0)).all(), "device verdicts differ from the oracle"
-            assert (so[sel][~fail] == exp[~fail]).all(), "device fixpoints differ from the oracle"
-            assert (res_h[sel, 1][~fail] == st[~fail]).all(), "device PROPS differ from the oracle"
-            done += nd_c.shape[0]
-        out["cpu_baseline"] = {"value": binds / spent, "unit": "propagations/s", "cores": 1, "kind": "port",
-                               "nodes_per_s": done / spent,
-                               "sample": f"first {done} of the {B} instances of this run, {spent:.1f} s on one host core; "
-                                         f"device results re-checked against it bit for bit"}
+        out["cpu_baseline"] = cpu_baseline(args, text, model, states_in, nodes, states_out, res_h)
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

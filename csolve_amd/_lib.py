@@ -73,6 +73,7 @@ def load_library():
     L.csgpu_model_root_propagate.argtypes = [vp, C.POINTER(i32)]
     L.csgpu_model_finalize.argtypes = [vp]
     L.csgpu_model_build_tables.argtypes = [vp]
+    L.csgpu_model_eval_clauses_host.argtypes = [vp, vp]
     L.csgpu_propagate_batch.argtypes = [vp, vp, vp, vp, vp, i64, vp]
     L.csgpu_eval_batch.argtypes = [vp, vp, vp, i64, vp]
     L.csgpu_eval_clauses.argtypes = [vp, vp, vp, vp]

@@ -35,7 +35,7 @@ struct csgpu_model {
   int finalized;
   cs_dev_image *img; /* search image */
   /* device copies of the image */
-  int *d_adj_off, *d_adj, *d_clause, *d_tree_off, *d_tnode, *d_tkid;
+  int *d_adj_off, *d_adj, *d_clause, *d_tree_off, *d_tnode, *d_tkid, *d_tree_want;
   cs_tables tab;
   size_t slice;      /* LDS bytes per node instance (16-byte aligned) */
   int has_tree_adj;  /* some adjacency entry is a tree clause */
@@ -107,9 +107,19 @@ extern "C" int csgpu_model_from_dump(const char *path, csgpu_model **out) {
   return wrap_model(host, 1, out);
 }
 
+/* internal (cs_internal.h): wrap a host model built by other host code of this package
+ * (the drop-in shim); takes ownership.  lists_final: keep the clause index it carries. */
+extern "C" int csgpu_model_from_host(cs_model *host, int lists_final, csgpu_model **out) {
+  if (host == NULL || out == NULL) return set_err(CSGPU_E_ARG, "null argument");
+  return wrap_model(host, lists_final, out);
+}
+
+extern "C" cs_model *csgpu_model_host(csgpu_model *m) { return m ? m->host : NULL; }
+
 static void free_device(csgpu_model *m) {
   (void)hipFree(m->d_adj_off); (void)hipFree(m->d_adj); (void)hipFree(m->d_clause);
-  (void)hipFree(m->d_tree_off); (void)hipFree(m->d_tnode); (void)hipFree(m->d_tkid);
+  (void)hipFree(m->d_tree_off); (void)hipFree(m->d_tnode); (void)hipFree(m->d_tkid); (void)hipFree(m->d_tree_want);
+  m->d_tree_want = NULL;
   (void)hipFree(m->d_one_in); (void)hipFree(m->d_one_out); (void)hipFree(m->d_one_node); (void)hipFree(m->d_one_res);
   m->d_adj_off = m->d_adj = m->d_clause = m->d_tree_off = m->d_tnode = m->d_tkid = NULL;
   m->d_one_in = m->d_one_out = NULL;
@@ -127,7 +137,12 @@ extern "C" void csgpu_model_free(csgpu_model *m) {
 }
 
 extern "C" int csgpu_model_num_vars(const csgpu_model *m) { return m ? m->host->n_vars : CSGPU_E_ARG; }
-extern "C" int csgpu_model_num_clauses(const csgpu_model *m) { return m ? m->host->n_clauses : CSGPU_E_ARG; }
+extern "C" int csgpu_model_num_clauses(const csgpu_model *m) {
+  if (m == NULL) return CSGPU_E_ARG;
+  /* the clause index is built on demand (it only depends on the trees and the domains) */
+  if (m->host->clause_node == NULL && m->host->root >= 0 && cs_model_index(m->host) != 0) return CSGPU_E_ARG;
+  return m->host->n_clauses;
+}
 extern "C" int csgpu_model_objective(const csgpu_model *m) { return m ? m->host->objective : CSGPU_E_ARG; }
 extern "C" int csgpu_model_objective_var(const csgpu_model *m) { return m ? m->host->obj_var : CSGPU_E_ARG; }
 
@@ -165,7 +180,7 @@ extern "C" int csgpu_model_device_info(const csgpu_model *m, int64_t info[8]) {
 /* ---- device image ------------------------------------------------------------------ */
 
 struct dev_tables_owner {
-  int *adj_off, *adj, *clause, *tree_off, *tnode, *tkid;
+  int *adj_off, *adj, *clause, *tree_off, *tnode, *tkid, *tree_want;
 };
 
 static int upload(const void *src, size_t bytes, int **dst) {
@@ -183,6 +198,7 @@ static int upload_image(const cs_dev_image *g, dev_tables_owner *o, cs_tables *t
   if ((rc = upload(g->tree_off, ((size_t)g->n_trees + 1) * 4, &o->tree_off))) return rc;
   if ((rc = upload(g->tnode, (size_t)(g->n_tnodes ? g->n_tnodes : 1) * 16, &o->tnode))) return rc;
   if ((rc = upload(g->tkid, (size_t)(g->n_tkids ? g->n_tkids : 1) * 4, &o->tkid))) return rc;
+  if ((rc = upload(g->tree_want, (size_t)(g->n_trees ? g->n_trees : 1) * 8, &o->tree_want))) return rc;
   t->n_vars = g->n_vars;
   t->n_clauses = g->n_clauses;
   t->n_words = (g->n_vars + 31) / 32;
@@ -192,12 +208,13 @@ static int upload_image(const cs_dev_image *g, dev_tables_owner *o, cs_tables *t
   t->tree_off = o->tree_off;
   t->tnode = (const int4 *)o->tnode;
   t->tkid = o->tkid;
+  t->tree_want = (const int2 *)o->tree_want;
   return CSGPU_OK;
 }
 
 static void free_tables(dev_tables_owner *o) {
   (void)hipFree(o->adj_off); (void)hipFree(o->adj); (void)hipFree(o->clause);
-  (void)hipFree(o->tree_off); (void)hipFree(o->tnode); (void)hipFree(o->tkid);
+  (void)hipFree(o->tree_off); (void)hipFree(o->tnode); (void)hipFree(o->tkid); (void)hipFree(o->tree_want);
 }
 
 static int lds_limit(size_t bytes, const void *func) {
@@ -244,6 +261,41 @@ extern "C" int csgpu_model_root_propagate(csgpu_model *m, int32_t *status) {
       *status = res.status < 0 ? -1 : res.props;
   }
   (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_res);
+  free_tables(&own);
+  cs_dev_image_free(g);
+  return rc;
+}
+
+extern "C" int csgpu_model_eval_clauses_host(csgpu_model *m, csgpu_val *vals) {
+  if (m == NULL || vals == NULL) return set_err(CSGPU_E_ARG, "null argument");
+  cs_model *h = m->host;
+  if (h->root < 0) return set_err(CSGPU_E_STATE, "model has no root");
+  if (!m->from_dump && cs_model_index(h) != 0) return set_err(CSGPU_E_ARG, "%s", h->err);
+  if (h->n_clauses == 0) return CSGPU_OK;
+  char err[200];
+  cs_dev_image *g = cs_dev_image_build(h, 0, NULL, err, sizeof err);
+  if (g == NULL) return set_err(CSGPU_E_LIMIT, "%s", err);
+  dev_tables_owner own;
+  cs_tables tab;
+  int rc = upload_image(g, &own, &tab);
+  cs_val *d_state = NULL, *d_vals = NULL;
+  const size_t lds = (size_t)h->n_vars * sizeof(cs_val) + 16;
+  hipError_t e = hipSuccess;
+  if (rc == CSGPU_OK) rc = lds_limit(lds, (const void *)cs_eval_clauses);
+  if (rc == CSGPU_OK &&
+      ((e = hipMalloc((void **)&d_state, (size_t)(h->n_vars ? h->n_vars : 1) * sizeof(cs_val))) != hipSuccess ||
+       (e = hipMalloc((void **)&d_vals, (size_t)h->n_clauses * sizeof(cs_val))) != hipSuccess ||
+       (e = hipMemcpy(d_state, h->dom, (size_t)h->n_vars * sizeof(cs_val), hipMemcpyHostToDevice)) != hipSuccess))
+    rc = set_err(CSGPU_E_HIP, "eval: %s", hipGetErrorString(e));
+  if (rc == CSGPU_OK) {
+    unsigned blocks = (unsigned)((h->n_clauses + CS_BLOCK - 1) / CS_BLOCK);
+    if (blocks > 1024u) blocks = 1024u;
+    hipLaunchKernelGGL(cs_eval_clauses, dim3(blocks), dim3(CS_BLOCK), lds, 0, tab, d_state, d_vals);
+    if ((e = hipGetLastError()) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess ||
+        (e = hipMemcpy(vals, d_vals, (size_t)h->n_clauses * sizeof(cs_val), hipMemcpyDeviceToHost)) != hipSuccess)
+      rc = set_err(CSGPU_E_HIP, "eval: %s", hipGetErrorString(e));
+  }
+  (void)hipFree(d_state); (void)hipFree(d_vals);
   free_tables(&own);
   cs_dev_image_free(g);
   return rc;
@@ -317,7 +369,7 @@ extern "C" int csgpu_model_finalize(csgpu_model *m) {
     free(vals); free(entailed);
   }
   m->d_adj_off = own.adj_off; m->d_adj = own.adj; m->d_clause = own.clause;
-  m->d_tree_off = own.tree_off; m->d_tnode = own.tnode; m->d_tkid = own.tkid;
+  m->d_tree_off = own.tree_off; m->d_tnode = own.tnode; m->d_tkid = own.tkid; m->d_tree_want = own.tree_want;
   if (rc != CSGPU_OK) return rc;
 
   const size_t slice = (size_t)h->n_vars * sizeof(cs_val) + 2 * (size_t)m->tab.n_words * sizeof(unsigned);

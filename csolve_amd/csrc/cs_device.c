@@ -109,7 +109,7 @@ static int32_t emit_tree(tree_ctx *t, int32_t node) {
 
 void cs_dev_image_free(cs_dev_image *g) {
   if (g == NULL) return;
-  free(g->adj_off); free(g->adj); free(g->clause); free(g->tree_off); free(g->tnode); free(g->tkid);
+  free(g->adj_off); free(g->adj); free(g->clause); free(g->tree_off); free(g->tnode); free(g->tkid); free(g->tree_want);
   free(g);
 }
 
@@ -130,16 +130,18 @@ cs_dev_image *cs_dev_image_build(const cs_model *m, int with_lists, const unsign
   t.local = (int32_t *)malloc((size_t)(m->n_nodes ? m->n_nodes : 1) * sizeof(int32_t));
   for (int32_t i = 0; i < m->n_nodes; i++) t.local[i] = -1;
   ibuf tree_off = { 0 };
+  ibuf want = { 0 };
 
   for (int32_t c = 0; c < m->n_clauses; c++) {
     int32_t root = m->clause_node[c];
     const cs_node *rn = &m->nodes[root];
     int32_t *rec = &g->clause[4 * c];
     int32_t a, b, d;
-    if ((entailed != NULL && entailed[c]) || (rn->op == CS_OP_CONST && rn->a == 1 && rn->b == 1)) {
+    const int want_true = m->clause_want == NULL || (m->clause_want[c].lo == 1 && m->clause_want[c].hi == 1);
+    if (want_true && ((entailed != NULL && entailed[c]) || (rn->op == CS_OP_CONST && rn->a == 1 && rn->b == 1))) {
       rec[0] = CS_CL_SKIP;
       g->n_skip++;
-    } else if (match_ne(m, root, &a, &b, &d)) {
+    } else if (want_true && match_ne(m, root, &a, &b, &d)) {
       rec[0] = CS_CL_NE; rec[1] = a; rec[2] = b; rec[3] = d;
       g->n_ne++;
     } else {
@@ -151,6 +153,8 @@ cs_dev_image *cs_dev_image_build(const cs_model *m, int with_lists, const unsign
       for (int32_t i = 0; i < t.touched.n; i++) t.local[t.touched.v[i]] = -1;
       if (len > g->max_tree) g->max_tree = len;
       rec[0] = CS_CL_TREE; rec[1] = g->n_trees;
+      ibuf_push(&want, m->clause_want ? m->clause_want[c].lo : 1);
+      ibuf_push(&want, m->clause_want ? m->clause_want[c].hi : 1);
       g->n_trees++;
       g->n_tree_clauses++;
     }
@@ -161,6 +165,7 @@ cs_dev_image *cs_dev_image_build(const cs_model *m, int with_lists, const unsign
   g->n_tnodes = t.tnode.n / 4;
   g->tkid = t.tkid.v ? t.tkid.v : (int32_t *)calloc(1, sizeof(int32_t));
   g->n_tkids = t.tkid.n;
+  g->tree_want = want.v ? want.v : (int32_t *)calloc(2, sizeof(int32_t));
   free(t.local);
   free(t.touched.v);
 

@@ -59,6 +59,7 @@ typedef struct cs_dev_image {
   int32_t *tree_off;    /* [n_trees+1] */
   int32_t *tnode;       /* [4*n_tnodes] */
   int32_t *tkid;        /* [n_tkids] */
+  int32_t *tree_want;   /* [2*n_trees] {lo,hi} pushed into each tree root, normally {1,1} */
 } cs_dev_image;
 
 /* with_lists = 0: clause-centric view only (root phase, lists not needed).

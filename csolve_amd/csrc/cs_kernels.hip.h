@@ -50,6 +50,7 @@ struct cs_tables {
   const int *tree_off;
   const int4 *tnode;
   const int *tkid;
+  const int2 *tree_want;
 };
 
 struct cs_node_in {
@@ -179,7 +180,10 @@ __device__ inline void cs_tree_revise(const cs_tables &T, int tree, cs_ctx &cx, 
   do {                                                                         \
     if (sp < CS_MAX_TREE_NODES) { S.node[sp] = (short)(K); S.want[sp] = (W); sp++; } \
   } while (0)
-  CS_PUSH(len - 1, cs_value(1));
+  {
+    const int2 rw = T.tree_want[tree];
+    CS_PUSH(len - 1, cs_interval(rw.x, rw.y));
+  }
   while (sp > 0 && !cx.fail) {
     sp--;
     const int k = S.node[sp];

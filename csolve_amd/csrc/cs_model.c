@@ -42,7 +42,7 @@ void cs_model_free(cs_model *m) {
   for (int32_t i = 0; i < m->n_vars; i++) free(m->names[i]);
   free(m->dom); free(m->names); free(m->prio); free(m->var_node);
   free(m->nodes); free(m->kids); free(m->top);
-  free(m->clause_node); free(m->list_off); free(m->list);
+  free(m->clause_node); free(m->list_off); free(m->list); free(m->clause_want);
   free(m->name_tab);
   free(m);
 }

@@ -57,6 +57,8 @@ typedef struct cs_model {
   int32_t *clause_node; /* [n_clauses] root node of each clause, root DFS order */
   int32_t *list_off;    /* [n_vars+1] */
   int32_t *list;        /* clause ids per variable, reference clause-list order */
+  cs_val *clause_want;  /* optional [n_clauses]: value pushed into each clause root; NULL = true
+                           for all (used by the single-operator entry points of the drop-in) */
   /* hash of names -> variable, open addressing */
   int32_t *name_tab;
   int32_t name_cap;

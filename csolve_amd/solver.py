@@ -106,6 +106,12 @@ class Model:
         check(load_library().csgpu_model_root_propagate(self._h, C.byref(st)))
         return st.value
 
+    def eval_clauses_host(self) -> np.ndarray:
+        """eval_<op> of every clause on the current root domains (no finalize needed)."""
+        out = np.empty((max(1, self.n_clauses), 2), dtype=np.int32)
+        check(load_library().csgpu_model_eval_clauses_host(self._h, out.ctypes.data))
+        return out[: self.n_clauses]
+
     def build_tables(self):
         """Host-only: clause lists + device tables in host memory (no HIP call)."""
         check(load_library().csgpu_model_build_tables(self._h))

@@ -98,6 +98,10 @@ int csgpu_model_device_info(const csgpu_model *m, int64_t info[8]);
  * which is the same state whenever the reference reaches its fixpoint within the limit.) */
 int csgpu_model_root_propagate(csgpu_model *m, int32_t *status);
 
+/* eval_<op> on the current root domains, host buffers, no finalize needed (variables may
+ * still be unbounded): vals[c] = interval value of clause c (eval.c:27-255).  Synchronous. */
+int csgpu_model_eval_clauses_host(csgpu_model *m, csgpu_val *vals);
+
 /* Host-only half of finalize: env_generate + clauses_init + construction of the device
  * tables in host memory (no HIP call).  csgpu_model_device_info works afterwards. */
 int csgpu_model_build_tables(csgpu_model *m);

@@ -16,7 +16,10 @@
  *        "@STATS {json}".
  *   csolve_ref model  <file> <out.model>
  *        dump the reference's post-root trees and clause lists as a cs_model file.
- *   csolve_ref walk   <file> <seed> <count> <out.bin> [general]
+ *   csolve_ref bench  <file> <instances.in> <results.out> [-c false]
+ *        replay given node instances through the reference's propagate_clauses(), timed
+ *        (the CPU baseline of bench.py; prints "@BENCH {json}").
+ *   csolve_ref walk   <file> <seed> <count> <out.bin> [-c false]
  *        seeded random assignment walks through the reference's
  *        propagate_clauses(); writes node instances (before, var, value,
  *        status/props, after).
@@ -399,6 +402,67 @@ static int cmd_walk(const char *path, uint64_t seed, long count, const char *out
   return 0;
 }
 
+/* ---- timed replay of given instances (the CPU baseline of bench.py) ------------ */
+
+#include <time.h>
+
+/* in : int32 LE: magic 'CSIN', n_vars, count, then per instance: var, value, before[n]{lo,hi}
+ * out: int32 LE: magic 'CSOU', n_vars, count, then per instance: status (-1 | PROPS), after[n]{lo,hi}
+ * prints "@BENCH {json}" with the time spent inside bind + propagate_clauses only */
+static int cmd_bench(const char *path, const char *in, const char *out) {
+  size_t size;
+  struct env_t *env;
+  struct constr_t *norm = root_phase(path, &size, &env);
+  if (norm == NULL) return 1;
+  FILE *f = fopen(in, "rb");
+  if (f == NULL) { fprintf(stderr, "csolve_ref: %s: %s\n", in, strerror(errno)); return 2; }
+  int32_t hdr[3];
+  if (fread(hdr, 4, 3, f) != 3 || hdr[0] != 0x4e495343 || (size_t)hdr[1] != size) {
+    fprintf(stderr, "csolve_ref: %s: bad instance file\n", in);
+    return 2;
+  }
+  const size_t count = (size_t)hdr[2], rec = 2 + 2 * size;
+  int32_t *inst = (int32_t *)malloc(count * rec * sizeof(int32_t));
+  if (fread(inst, sizeof(int32_t), count * rec, f) != count * rec) { fprintf(stderr, "csolve_ref: short read\n"); return 2; }
+  fclose(f);
+  int32_t *res = (int32_t *)malloc(count * (1 + 2 * size) * sizeof(int32_t));
+  void *marker = alloc(0);
+  bind_level_set(0);
+  uint64_t binds = 0, fails = 0;
+  struct timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (size_t i = 0; i < count; i++) {
+    const int32_t *r = &inst[i * rec];
+    for (size_t v = 0; v < size; v++) {
+      env[v].val->constr.term.val.lo = r[2 + 2 * v];
+      env[v].val->constr.term.val.hi = r[3 + 2 * v];
+    }
+    struct env_t *var = &env[r[0]];
+    uint64_t before = stat_get_props();
+    bind(var, VALUE(r[1]), NULL);
+    prop_result_t p = propagate_clauses(&var->clauses);
+    int32_t *o = &res[i * (1 + 2 * size)];
+    o[0] = p == PROP_ERROR ? -1 : (int32_t)(stat_get_props() - before);
+    binds += stat_get_props() - before;
+    fails += p == PROP_ERROR;
+    for (size_t v = 0; v < size; v++) {
+      o[1 + 2 * v] = env[v].val->constr.term.val.lo;
+      o[2 + 2 * v] = env[v].val->constr.term.val.hi;
+    }
+    unbind(0); unpatch(0); dealloc(marker);
+  }
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  double secs = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+  f = fopen(out, "wb");
+  if (f == NULL) { fprintf(stderr, "csolve_ref: %s: %s\n", out, strerror(errno)); return 2; }
+  int32_t ohdr[3] = { 0x554f5343, (int32_t)size, (int32_t)count };
+  fwrite(ohdr, 4, 3, f);
+  fwrite(res, sizeof(int32_t), count * (1 + 2 * size), f);
+  fclose(f);
+  printf("@BENCH {\"instances\": %zu, \"seconds\": %.6f, \"binds\": %lu, \"fails\": %lu}\n", count, secs, binds, fails);
+  return 0;
+}
+
 /* ---- commands --------------------------------------------------------------- */
 
 static bool parse_bool(const char *s) { return strcmp(s, "true") == 0 || strcmp(s, "1") == 0; }
@@ -420,7 +484,7 @@ int main(int argc, char **argv) {
                        STRATEGY_COMPUTE_WEIGHTS_DEFAULT, STRATEGY_RESTART_FREQUENCY_DEFAULT,
                        STRATEGY_ORDER_DEFAULT, TIME_MAX_DEFAULT };
   const char *cmd = argv[1], *path = argv[2];
-  int first_opt = strcmp(cmd, "solve") == 0 ? 3 : (strcmp(cmd, "model") == 0 ? 4 : 6);
+  int first_opt = strcmp(cmd, "solve") == 0 ? 3 : (strcmp(cmd, "model") == 0 ? 4 : (strcmp(cmd, "bench") == 0 ? 5 : 6));
   for (int i = first_opt; i + 1 < argc; i += 2) {
     if (strcmp(argv[i], "-c") == 0) o.conflicts = parse_bool(argv[i + 1]);
     else if (strcmp(argv[i], "-f") == 0) o.prefer_failing = parse_bool(argv[i + 1]);
@@ -431,6 +495,11 @@ int main(int argc, char **argv) {
     else { fprintf(stderr, "csolve_ref: unknown option %s\n", argv[i]); return 2; }
   }
   reference_init(&o);
+
+  if (strcmp(cmd, "bench") == 0) {
+    if (argc < 5) { fprintf(stderr, "usage: csolve_ref bench <file> <instances.in> <results.out>\n"); return 2; }
+    return cmd_bench(path, argv[3], argv[4]);
+  }
 
   if (strcmp(cmd, "walk") == 0) {
     if (argc < 6) { fprintf(stderr, "usage: csolve_ref walk <file> <seed> <count> <out>\n"); return 2; }
@@ -453,6 +522,17 @@ int main(int argc, char **argv) {
   if (strcmp(cmd, "solve") == 0) {
     if (norm != NULL) solve(size, env, norm); /* second half of the Input action (parser.y:86) */
     fflush(stdout);
+#ifdef CS_DROPIN_BUILD
+    {
+      /* this build links the reference DRIVER against libcsolve_dropin.so: report how often the
+       * driver went through the GPU entry points */
+      extern void csolve_dropin_counters(uint64_t out[4]);
+      uint64_t k[4];
+      csolve_dropin_counters(k);
+      printf("@DROPIN {\"propagate_clauses\": %lu, \"propagate\": %lu, \"eval\": %lu, \"single_op\": %lu}\n",
+             k[0], k[1], k[2], k[3]);
+    }
+#endif
     printf("@STATS {\"feasible_root\": %s, \"calls\": %lu, \"cuts\": %lu, \"props\": %lu, \"confl\": %lu, "
            "\"restarts\": %lu, \"solutions\": %lu, \"best\": %d, \"timeout\": %s}\n",
            norm != NULL ? "true" : "false", stat_get_calls(), stat_get_cuts(), stat_get_props(),

@@ -32,6 +32,7 @@ static int set_err(int code, const char *fmt, ...) {
 struct csgpu_model {
   cs_model *host;
   int from_dump;     /* clause lists came with the file: keep them */
+  int not_root;      /* host domains are not the root state: no entailed-clause elimination */
   int finalized;
   cs_dev_image *img; /* search image */
   /* device copies of the image */
@@ -109,9 +110,11 @@ extern "C" int csgpu_model_from_dump(const char *path, csgpu_model **out) {
 
 /* internal (cs_internal.h): wrap a host model built by other host code of this package
  * (the drop-in shim); takes ownership.  lists_final: keep the clause index it carries. */
-extern "C" int csgpu_model_from_host(cs_model *host, int lists_final, csgpu_model **out) {
+extern "C" int csgpu_model_from_host(cs_model *host, int lists_final, int domains_are_root, csgpu_model **out) {
   if (host == NULL || out == NULL) return set_err(CSGPU_E_ARG, "null argument");
-  return wrap_model(host, lists_final, out);
+  int rc = wrap_model(host, lists_final, out);
+  if (rc == CSGPU_OK) (*out)->not_root = !domains_are_root;
+  return rc;
 }
 
 extern "C" cs_model *csgpu_model_host(csgpu_model *m) { return m ? m->host : NULL; }
@@ -329,7 +332,7 @@ extern "C" int csgpu_model_finalize(csgpu_model *m) {
 
   dev_tables_owner own;
   int rc = upload_image(m->img, &own, &m->tab);
-  if (rc == CSGPU_OK && h->n_clauses > 0) {
+  if (rc == CSGPU_OK && h->n_clauses > 0 && !m->not_root) {
     /* Clauses that already evaluate to true in the root state are entailed for the whole
      * search: evaluate every clause once on the device and drop those from the tables. */
     cs_val *d_state = NULL, *d_vals = NULL;

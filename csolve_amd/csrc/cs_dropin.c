@@ -199,7 +199,7 @@ void csolve_dropin_detach(void) {
   g_size = 0;
 }
 
-int csolve_dropin_attach(struct env_t *env, size_t size, struct constr_t *root) {
+static int attach(struct env_t *env, size_t size, struct constr_t *root, int at_root) {
   csolve_dropin_detach();
   flat f;
   memset(&f, 0, sizeof f);
@@ -239,7 +239,7 @@ int csolve_dropin_attach(struct env_t *env, size_t size, struct constr_t *root) 
   pmap_free(&clause_ids);
   flat_done(&f);
 
-  if (csgpu_model_from_host(f.m, 1, &g_model) != CSGPU_OK) fatal_gpu("attach");
+  if (csgpu_model_from_host(f.m, 1, at_root, &g_model) != CSGPU_OK) fatal_gpu("attach");
   if (csgpu_model_finalize(g_model) != CSGPU_OK) fatal_gpu("attach");
   g_env = env;
   g_size = size;
@@ -248,6 +248,9 @@ int csolve_dropin_attach(struct env_t *env, size_t size, struct constr_t *root) 
   g_out = (csgpu_val *)malloc((size ? size : 1) * sizeof *g_out);
   return 0;
 }
+
+/* explicit attach: called by the driver between clauses_init() and solve(), i.e. at the root */
+int csolve_dropin_attach(struct env_t *env, size_t size, struct constr_t *root) { return attach(env, size, root, 1); }
 
 /* find the environment array from the terminals under the last root (zero-patch attach) */
 static void collect_env(struct constr_t *c, pmap *seen, struct env_t **lo, struct env_t **hi) {
@@ -279,7 +282,8 @@ static void lazy_attach(const struct clause_list_t *clauses) {
   struct env_t *owner = (struct env_t *)((char *)clauses - offsetof(struct env_t, clauses));
   if (lo == NULL || owner < lo) lo = owner;
   if (hi == NULL || owner > hi) hi = owner;
-  csolve_dropin_attach(lo, (size_t)(hi - lo) + 1, g_root);
+  /* the driver has already bound the branching variable: not the root state */
+  attach(lo, (size_t)(hi - lo) + 1, g_root, 0);
 }
 
 /* ---- arithmetic (replaces src/arith.c) -------------------------------------------------------
@@ -308,13 +312,13 @@ prop_result_t propagate_clauses(const struct clause_list_t *clauses) {
   csgpu_result res;
   g_calls[0]++;
   if (csgpu_propagate_one(g_model, g_state, node, g_out, &res) != CSGPU_OK) fatal_gpu("propagate_clauses");
+  props += (uint64_t)res.props; /* narrowings of an inconsistent node count too (propagate.c:78) */
   if (res.status < 0) return PROP_ERROR;
   for (size_t i = 0; i < g_size; i++)
     if (g_out[i].lo != g_state[i].lo || g_out[i].hi != g_state[i].hi) {
       struct val_t v = { g_out[i].lo, g_out[i].hi };
       bind(&g_env[i], v, NULL);
     }
-  props += (uint64_t)res.props;
   return res.props;
 }
 
@@ -328,7 +332,7 @@ static prop_result_t propagate_tree(struct constr_t *constr, struct val_t want, 
   flat_slots(&f, constr);
   csgpu_model *gm = NULL;
   cs_model *hm = f.m;
-  if (csgpu_model_from_host(hm, 0, &gm) != CSGPU_OK) fatal_gpu("propagate");
+  if (csgpu_model_from_host(hm, 0, 0, &gm) != CSGPU_OK) fatal_gpu("propagate");
   if (want.lo != 1 || want.hi != 1) {
     /* a single tree pushed with an arbitrary value: one clause, its want */
     if (csgpu_model_num_clauses(gm) < 0) fatal_gpu("propagate");
@@ -410,7 +414,7 @@ static struct val_t eval_tree(const struct constr_t *constr) {
   }
   flat_slots(&f, (struct constr_t *)constr);
   csgpu_model *gm = NULL;
-  if (csgpu_model_from_host(f.m, 0, &gm) != CSGPU_OK) fatal_gpu("eval");
+  if (csgpu_model_from_host(f.m, 0, 0, &gm) != CSGPU_OK) fatal_gpu("eval");
   int n = csgpu_model_num_clauses(gm);
   csgpu_val *vals = (csgpu_val *)malloc((size_t)(n > 0 ? n : 1) * sizeof *vals);
   if (n < 0 || csgpu_model_eval_clauses_host(gm, vals) != CSGPU_OK) fatal_gpu("eval");

@@ -10,7 +10,9 @@
 extern "C" {
 #endif
 
-int csgpu_model_from_host(cs_model *host, int lists_final, csgpu_model **out);
+/* domains_are_root = 0: the domains the model carries belong to some search node, so clauses
+ * entailed by them must NOT be dropped at finalize */
+int csgpu_model_from_host(cs_model *host, int lists_final, int domains_are_root, csgpu_model **out);
 cs_model *csgpu_model_host(csgpu_model *m);
 
 #ifdef __cplusplus

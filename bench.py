@@ -153,6 +153,62 @@ def cpu_baseline(args, text, model, states_in, nodes, states_out, res_h):
                       f"on one host core; device results re-checked against it bit for bit"}
 
 
+def search_workload(args, rank, world, local, dist):
+    """BASELINE configs[3]-style run: queens-N ALL, the whole search tree sharded over the ranks
+    (csolve_amd/parallel.py: seeding from rank 0, stealing of open states, shared incumbent).
+    Strong scaling: the tree is fixed, every step is one complete search."""
+    from csolve_amd.parallel import ShardedSearch
+    from csolve_amd.solver import Search
+    text = problems.queens(args.search_queens, "ALL")
+    model = solve_root(text)
+    n = model.n_vars
+    comm = "cpu" if args.comm == "gloo" else "cuda"
+
+    def once():
+        eng = Search(model, args.pool, args.children)
+        sh = ShardedSearch(eng, model.objective, n, rank, world, dist, engine_device="cuda", comm_device=comm,
+                           slice_iterations=args.slice, seed_states_per_rank=256, low_water=4096)
+        local_stats, totals = sh.run(model.root_state())
+        eng.close()
+        return local_stats, totals, sh
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        once()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        local_stats, totals, sh = once()
+    barrier()
+    t1 = time.perf_counter()
+    el = torch.tensor([t1 - t0], dtype=torch.float64, device=comm)
+    moved = torch.tensor([sh.states_moved], dtype=torch.int64, device=comm)
+    share = torch.tensor([local_stats["nodes"]], dtype=torch.int64, device=comm)
+    if dist is not None:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(moved, op=dist.ReduceOp.SUM)
+        gathered = torch.empty(world, dtype=torch.int64, device=comm)
+        dist.all_gather_into_tensor(gathered, share)
+        share = gathered
+    elapsed = float(el.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "constraint propagations/sec + nodes/sec, queens-N, 1/2/4/8 MI355X",
+            "value": totals["props"] * args.steps / elapsed, "unit": "propagations/s",
+            "nodes_per_s": totals["nodes"] * args.steps / elapsed, "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": f"queens-{args.search_queens} ALL, full search sharded GPU-per-subtree "
+                                   f"(BASELINE configs[3] shape)", "solutions": totals["solutions"],
+                       "nodes": totals["nodes"], "cuts": totals["cuts"], "props": totals["props"],
+                       "iterations": totals["iterations"], "states_moved_between_ranks": int(moved.item()),
+                       "nodes_per_rank": share.cpu().tolist(), "comm": args.comm}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -162,6 +218,13 @@ def main():
     ap.add_argument("--instances", type=int, default=1 << 18, help="node instances per GPU")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--workload", choices=["propagate", "search"], default="propagate")
+    ap.add_argument("--search-queens", type=int, default=13)
+    ap.add_argument("--pool", type=int, default=1 << 21)
+    ap.add_argument("--children", type=int, default=1 << 17)
+    ap.add_argument("--slice", type=int, default=32, help="search iterations between rank exchanges")
+    ap.add_argument("--comm", choices=["nccl", "gloo"], default="nccl")
+    ap.add_argument("--same-device", action="store_true", help="all ranks on cuda:0 (rehearsal on a 1-GPU box, use --comm gloo)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -169,11 +232,21 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.same_device:
+        local = 0
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.comm == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
+    if args.workload == "search":
+        search_workload(args, rank, world, local, dist)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     n_q = args.queens
     text = problems.queens(n_q)

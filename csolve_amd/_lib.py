@@ -24,6 +24,12 @@ class Node(C.Structure):
     _fields_ = [("var", C.c_int32), ("lo", C.c_int32), ("hi", C.c_int32), ("parent", C.c_int32)]
 
 
+class SearchStats(C.Structure):
+    _fields_ = [("nodes", C.c_uint64), ("cuts", C.c_uint64), ("props", C.c_uint64), ("revisions", C.c_uint64),
+                ("solutions", C.c_uint64), ("iterations", C.c_uint64), ("pool", C.c_int64), ("pool_peak", C.c_int64),
+                ("best", C.c_int32), ("done", C.c_int32)]
+
+
 class Result(C.Structure):
     _fields_ = [("status", C.c_int32), ("props", C.c_int32), ("revisions", C.c_int32), ("rounds", C.c_int32)]
 
@@ -75,8 +81,18 @@ def load_library():
     L.csgpu_model_build_tables.argtypes = [vp]
     L.csgpu_model_eval_clauses_host.argtypes = [vp, vp]
     L.csgpu_propagate_batch.argtypes = [vp, vp, vp, vp, vp, i64, vp]
+    L.csgpu_propagate_batch_obj.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, vp]
     L.csgpu_eval_batch.argtypes = [vp, vp, vp, i64, vp]
     L.csgpu_eval_clauses.argtypes = [vp, vp, vp, vp]
+    L.csgpu_search_create.argtypes = [vp, i64, i64, C.POINTER(vp)]
+    L.csgpu_search_free.argtypes = [vp]
+    L.csgpu_search_free.restype = None
+    L.csgpu_search_put.argtypes = [vp, vp, i64]
+    L.csgpu_search_take.argtypes = [vp, vp, i64, C.POINTER(i64)]
+    L.csgpu_search_set_best.argtypes = [vp, i32]
+    L.csgpu_search_run.argtypes = [vp, i64, C.POINTER(SearchStats)]
+    L.csgpu_search_solutions.argtypes = [vp, vp, i64]
+    L.csgpu_search_solutions.restype = i64
     L.csgpu_propagate_one.argtypes = [vp, vp, Node, vp, C.POINTER(Result)]
     _lib = L
     return L

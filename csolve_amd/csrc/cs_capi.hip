@@ -22,6 +22,9 @@ static int set_err(int code, const char *fmt, ...) {
   return code;
 }
 
+/* shared with cs_search.hip */
+extern "C" int csgpu_internal_set_error(int code, const char *msg) { return set_err(code, "%s", msg); }
+
 #define HIP_TRY(expr)                                                          \
   do {                                                                         \
     hipError_t e_ = (expr);                                                    \
@@ -212,6 +215,9 @@ static int upload_image(const cs_dev_image *g, dev_tables_owner *o, cs_tables *t
   t->tnode = (const int4 *)o->tnode;
   t->tkid = o->tkid;
   t->tree_want = (const int2 *)o->tree_want;
+  t->obj_var = -1;
+  t->obj_lo = CS_DOM_MIN;
+  t->obj_hi = CS_DOM_MAX;
   return CSGPU_OK;
 }
 
@@ -405,6 +411,13 @@ extern "C" int csgpu_model_finalize(csgpu_model *m) {
 
 extern "C" int csgpu_propagate_batch(const csgpu_model *m, const csgpu_val *d_states_in, const csgpu_node *d_nodes,
                                      csgpu_val *d_states_out, csgpu_result *d_results, int64_t batch, void *stream) {
+  return csgpu_propagate_batch_obj(m, d_states_in, d_nodes, d_states_out, d_results, batch, CS_DOM_MIN, CS_DOM_MAX,
+                                   stream);
+}
+
+extern "C" int csgpu_propagate_batch_obj(const csgpu_model *m, const csgpu_val *d_states_in, const csgpu_node *d_nodes,
+                                         csgpu_val *d_states_out, csgpu_result *d_results, int64_t batch,
+                                         int32_t obj_lo, int32_t obj_hi, void *stream) {
   if (m == NULL || d_states_in == NULL || d_nodes == NULL || d_states_out == NULL || d_results == NULL || batch < 0)
     return set_err(CSGPU_E_ARG, "null argument");
   if (!m->finalized) return set_err(CSGPU_E_STATE, "model is not finalized");
@@ -423,11 +436,17 @@ extern "C" int csgpu_propagate_batch(const csgpu_model *m, const csgpu_val *d_st
   const cs_node_in *nodes = (const cs_node_in *)d_nodes;
   cs_val *out = (cs_val *)d_states_out;
   cs_node_out *res = (cs_node_out *)d_results;
+  cs_tables tab = m->tab;
+  if (m->host->obj_var >= 0 && (obj_lo != CS_DOM_MIN || obj_hi != CS_DOM_MAX)) {
+    tab.obj_var = m->host->obj_var;
+    tab.obj_lo = obj_lo;
+    tab.obj_hi = obj_hi;
+  }
   if (m->has_tree_adj)
-    hipLaunchKernelGGL(cs_propagate_events<true>, dim3((unsigned)blocks), dim3(CS_BLOCK), lds, s, m->tab, in, nodes, out,
+    hipLaunchKernelGGL(cs_propagate_events<true>, dim3((unsigned)blocks), dim3(CS_BLOCK), lds, s, tab, in, nodes, out,
                        res, (long long)batch);
   else
-    hipLaunchKernelGGL(cs_propagate_events<false>, dim3((unsigned)blocks), dim3(CS_BLOCK), lds, s, m->tab, in, nodes, out,
+    hipLaunchKernelGGL(cs_propagate_events<false>, dim3((unsigned)blocks), dim3(CS_BLOCK), lds, s, tab, in, nodes, out,
                        res, (long long)batch);
   HIP_TRY(hipGetLastError());
   return CSGPU_OK;

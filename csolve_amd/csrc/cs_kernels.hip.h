@@ -51,6 +51,9 @@ struct cs_tables {
   const int4 *tnode;
   const int *tkid;
   const int2 *tree_want;
+  /* objective bound applied to every node before it is propagated (objective_update_val,
+   * reference src/objective.c:101-126): dom[obj_var] is intersected with [obj_lo, obj_hi] */
+  int obj_var, obj_lo, obj_hi;
 };
 
 struct cs_node_in {
@@ -332,6 +335,17 @@ __global__ __launch_bounds__(CS_BLOCK) void cs_propagate_events(cs_tables T, con
       }
     }
     cs_wave_sync();
+    if (T.obj_var >= 0 && lane == 0) {
+      /* untrailed tightening of "<obj>" by the incumbent; the variable counts as changed only
+       * if the bound actually moved (csolve.c:251-252 then re-propagates its clauses) */
+      cs_val d = dom[T.obj_var];
+      const int nl = cs_max(d.lo, T.obj_lo), nh = cs_min(d.hi, T.obj_hi);
+      if (nl != d.lo || nh != d.hi) {
+        dom[T.obj_var] = cs_interval(nl, nh);
+        atomicOr(&mask_a[T.obj_var >> 5], 1u << (T.obj_var & 31));
+      }
+    }
+    cs_wave_sync();
 
     unsigned *cur = mask_a, *nxt = mask_b;
     int rounds = 0, failed = 0;
@@ -375,13 +389,18 @@ __global__ __launch_bounds__(CS_BLOCK) void cs_propagate_events(cs_tables T, con
       props += __shfl_xor(props, off);
       revs += __shfl_xor(revs, off);
     }
+    int open_vars = 0;
     if (!failed) {
       cs_val *dst = states_out + (size_t)node * n;
-      for (int v = lane; v < n; v += CS_WAVE) dst[v] = dom[v];
+      for (int v = lane; v < n; v += CS_WAVE) {
+        const cs_val d = dom[v];
+        dst[v] = d;
+        open_vars += __popcll(__ballot(d.lo != d.hi));
+      }
     }
     if (lane == 0) {
       cs_node_out r;
-      r.status = failed ? -1 : 0;
+      r.status = failed ? -1 : open_vars;
       r.props = props;
       r.revisions = revs;
       r.rounds = rounds;

@@ -1,0 +1,459 @@
+/* cs_search.hip -- device-resident tree search on top of the batched propagation ABI.
+ * Reference behaviour being mirrored: solve() (reference src/csolve.c:398-476) -- branch on a
+ * variable, try every value of its interval (step_val 331-338), propagate each (check_assignment
+ * 247-261), count CALLS/CUTS (65-73, 255-258), accept complete assignments whose root evaluates to
+ * true (update_solution 222-244), keep the incumbent (objective.c:81-126).  The reference walks
+ * this tree depth-first one node at a time; here whole frontiers are expanded per launch. */
+#include <hip/hip_runtime.h>
+
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/csolve_gpu.h"
+#include "cs_arith.h"
+#include "cs_frontend.h"
+
+#define SB 256 /* threads per block of the bookkeeping kernels */
+
+enum { C_SURVIVORS = 0, C_COMPLETE, C_CUTS, C_PROPS, C_REVS, C_SOLUTIONS, C_STORED, C_TOTAL_CHILDREN, C_COUNT };
+
+struct csgpu_search {
+  const csgpu_model *m;
+  int n, objective, obj_var;
+  int64_t cap, max_children, max_parents, max_width;
+  cs_val *pool;
+  int64_t top, peak;
+  int *d_branch_var, *d_child_count, *d_child_off;
+  csgpu_node *d_nodes;
+  cs_val *d_child_states, *d_complete_states;
+  csgpu_result *d_results;
+  int *d_dest, *d_complete_list, *d_truth;
+  unsigned long long *d_counters; /* [C_COUNT] */
+  int *d_best;
+  int32_t *d_solutions;           /* [max_solutions][n] */
+  int64_t max_solutions;
+  csgpu_search_stats st;
+};
+
+extern "C" int csgpu_internal_set_error(int code, const char *msg); /* cs_capi.hip */
+static int fail(int code, const char *msg) { return csgpu_internal_set_error(code, msg); }
+
+#define SPLIT_WIDTH 256 /* wider intervals are halved instead of enumerated (csolve.c:121-150 style) */
+#define HIP_OK(expr)                                                           \
+  do {                                                                         \
+    hipError_t e_ = (expr);                                                    \
+    if (e_ != hipSuccess) return fail(CSGPU_E_HIP, hipGetErrorString(e_));     \
+  } while (0)
+
+/* one wave per parent: the open variable with the smallest interval (ties: lowest index), the
+ * reference's "-o smallest-domain" idea (strategy.c:85-91) as a pure function of the state.
+ * Intervals wider than SPLIT_WIDTH are halved (two children) instead of enumerated. */
+__global__ __launch_bounds__(SB) void cs_branch(const cs_val *__restrict__ pool, long long first_row, int parents,
+                                                int n, int *__restrict__ branch_var, int *__restrict__ child_count) {
+  const int lane = threadIdx.x & 63;
+  const int p = blockIdx.x * (SB / 64) + (threadIdx.x >> 6);
+  if (p >= parents) return;
+  const cs_val *row = pool + (size_t)(first_row + p) * n;
+  /* key = (width-1) * 2^32 + index, minimised over the wave */
+  unsigned long long best = ~0ull;
+  for (int v = lane; v < n; v += 64) {
+    const cs_val d = row[v];
+    if (d.lo != d.hi) {
+      const unsigned long long w = (unsigned long long)((long long)d.hi - (long long)d.lo);
+      const unsigned long long key = (w << 32) | (unsigned)v;
+      best = key < best ? key : best;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long other = __shfl_xor(best, o);
+    best = other < best ? other : best;
+  }
+  if (lane == 0) {
+    if (best == ~0ull) {
+      branch_var[p] = -1;
+      child_count[p] = 0;
+    } else {
+      const unsigned long long width = (best >> 32) + 1ull;
+      branch_var[p] = (int)(best & 0xffffffffu);
+      child_count[p] = width > SPLIT_WIDTH ? 2 : (int)width;
+    }
+  }
+}
+
+/* exclusive scan of child_count[0..parents) by one block; total -> counters[C_TOTAL_CHILDREN] */
+__global__ __launch_bounds__(1024) void cs_scan(const int *__restrict__ count, int parents, int *__restrict__ off,
+                                                unsigned long long *__restrict__ counters) {
+  __shared__ long long part[1024];
+  const int t = threadIdx.x;
+  const int per = (parents + 1023) / 1024;
+  const int b = t * per, e = min(parents, b + per);
+  long long sum = 0;
+  for (int i = b; i < e; i++) sum += count[i];
+  part[t] = sum;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    long long v = t >= d ? part[t - d] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  long long run = part[t] - sum;
+  for (int i = b; i < e; i++) {
+    off[i] = (int)run;
+    run += count[i];
+  }
+  if (t == 1023) {
+    off[parents] = (int)part[1023];
+    counters[C_TOTAL_CHILDREN] = (unsigned long long)part[1023];
+  }
+}
+
+/* one wave per parent writes its children {var, value, value, parent_row} */
+__global__ __launch_bounds__(SB) void cs_emit(const cs_val *__restrict__ pool, long long first_row, int parents, int n,
+                                              const int *__restrict__ branch_var, const int *__restrict__ child_off,
+                                              csgpu_node *__restrict__ nodes, int low_values_last) {
+  const int lane = threadIdx.x & 63;
+  const int p = blockIdx.x * (SB / 64) + (threadIdx.x >> 6);
+  if (p >= parents) return;
+  const int var = branch_var[p];
+  if (var < 0) return;
+  const cs_val d = pool[(size_t)(first_row + p) * n + var];
+  const int beg = child_off[p], cnt = child_off[p + 1] - beg;
+  const long long width = (long long)d.hi - (long long)d.lo + 1;
+  if (width > SPLIT_WIDTH) { /* two halves, lower half first */
+    const int mid = (int)(((long long)d.lo + (long long)d.hi) >> 1);
+    if (lane < 2) {
+      /* the pool is LIFO and later children land higher: the half written last is explored first */
+      const int lower = low_values_last ? lane == 1 : lane == 0;
+      csgpu_node nd;
+      nd.var = var;
+      nd.lo = lower ? d.lo : mid + 1;
+      nd.hi = lower ? mid : d.hi;
+      nd.parent = (int)(first_row + p);
+      nodes[beg + lane] = nd;
+    }
+    return;
+  }
+  for (int k = lane; k < cnt; k += 64) {
+    csgpu_node nd;
+    const int value = low_values_last ? d.hi - k : d.lo + k;
+    nd.var = var;
+    nd.lo = value;
+    nd.hi = value;
+    nd.parent = (int)(first_row + p);
+    nodes[beg + k] = nd;
+  }
+}
+
+/* classify the children: survivors get a pool row, complete ones go to the solution check */
+__global__ __launch_bounds__(SB) void cs_select(const csgpu_result *__restrict__ res, int children, long long new_top,
+                                                int *__restrict__ dest, int *__restrict__ complete_list,
+                                                unsigned long long *__restrict__ counters) {
+  __shared__ int s_surv[SB], s_comp[SB];
+  __shared__ unsigned long long s_base[2];
+  __shared__ unsigned long long s_sum[3];
+  const int t = threadIdx.x, i = blockIdx.x * SB + t;
+  int status = -2, props = 0, revs = 0;
+  if (i < children) {
+    status = res[i].status;
+    props = res[i].props;
+    revs = res[i].revisions;
+  }
+  const int surv = status > 0, comp = status == 0, cut = status == -1;
+  s_surv[t] = surv;
+  s_comp[t] = comp;
+  if (t < 3) s_sum[t] = 0ull;
+  __syncthreads();
+  for (int d = 1; d < SB; d <<= 1) {
+    int a = t >= d ? s_surv[t - d] : 0, b = t >= d ? s_comp[t - d] : 0;
+    __syncthreads();
+    s_surv[t] += a;
+    s_comp[t] += b;
+    __syncthreads();
+  }
+  /* wave-level partial sums of the statistics, then one atomic per block */
+  unsigned long long pc = (unsigned long long)cut, pp = (unsigned long long)props, pr = (unsigned long long)revs;
+  for (int o = 32; o > 0; o >>= 1) {
+    pc += __shfl_xor(pc, o);
+    pp += __shfl_xor(pp, o);
+    pr += __shfl_xor(pr, o);
+  }
+  if ((t & 63) == 0) {
+    atomicAdd(&s_sum[0], pc);
+    atomicAdd(&s_sum[1], pp);
+    atomicAdd(&s_sum[2], pr);
+  }
+  __syncthreads();
+  if (t == 0) {
+    s_base[0] = atomicAdd(&counters[C_SURVIVORS], (unsigned long long)s_surv[SB - 1]);
+    s_base[1] = atomicAdd(&counters[C_COMPLETE], (unsigned long long)s_comp[SB - 1]);
+    atomicAdd(&counters[C_CUTS], s_sum[0]);
+    atomicAdd(&counters[C_PROPS], s_sum[1]);
+    atomicAdd(&counters[C_REVS], s_sum[2]);
+  }
+  __syncthreads();
+  if (i < children) {
+    dest[i] = surv ? (int)(new_top + (long long)s_base[0] + s_surv[t] - 1) : -1;
+    if (comp) complete_list[s_base[1] + s_comp[t] - 1] = i;
+  }
+}
+
+/* one wave per child: copy survivors into their pool rows */
+__global__ __launch_bounds__(SB) void cs_scatter(const cs_val *__restrict__ child_states, const int *__restrict__ dest,
+                                                 int children, int n, cs_val *__restrict__ pool) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * (SB / 64) + (threadIdx.x >> 6);
+  if (i >= children) return;
+  const int d = dest[i];
+  if (d < 0) return;
+  const cs_val *src = child_states + (size_t)i * n;
+  cs_val *dst = pool + (size_t)d * n;
+  for (int v = lane; v < n; v += 64) dst[v] = src[v];
+}
+
+/* one wave per complete child: gather it for the root evaluation */
+__global__ __launch_bounds__(SB) void cs_gather_complete(const cs_val *__restrict__ child_states,
+                                                         const int *__restrict__ list, int count, int n,
+                                                         cs_val *__restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * (SB / 64) + (threadIdx.x >> 6);
+  if (i >= count) return;
+  const cs_val *src = child_states + (size_t)list[i] * n;
+  cs_val *dst = out + (size_t)i * n;
+  for (int v = lane; v < n; v += 64) dst[v] = src[v];
+}
+
+/* accept the complete children whose root evaluated to true: count, incumbent, store some */
+__global__ __launch_bounds__(SB) void cs_accept(const cs_val *__restrict__ complete, const int *__restrict__ truth,
+                                                int count, int n, int objective, int obj_var, int *__restrict__ best,
+                                                unsigned long long *__restrict__ counters,
+                                                int32_t *__restrict__ solutions, long long max_solutions) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * (SB / 64) + (threadIdx.x >> 6);
+  if (i >= count || truth[i] != 1) return;
+  const cs_val *row = complete + (size_t)i * n;
+  long long slot = -1;
+  if (lane == 0) {
+    atomicAdd(&counters[C_SOLUTIONS], 1ull);
+    if (objective == CS_OBJ_MIN) atomicMin(best, row[obj_var].lo);
+    if (objective == CS_OBJ_MAX) atomicMax(best, row[obj_var].hi);
+    slot = (long long)atomicAdd(&counters[C_STORED], 1ull);
+  }
+  slot = __shfl(slot, 0);
+  if (slot < max_solutions)
+    for (int v = lane; v < n; v += 64) solutions[(size_t)slot * n + v] = row[v].lo;
+}
+
+/* move the newest `count` rows into the hole left by taking the oldest ones */
+__global__ __launch_bounds__(SB) void cs_move_rows(cs_val *__restrict__ pool, long long src_row, long long dst_row,
+                                                   int count, int n) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * (SB / 64) + (threadIdx.x >> 6);
+  if (i >= count) return;
+  const cs_val *src = pool + (size_t)(src_row + i) * n;
+  cs_val *dst = pool + (size_t)(dst_row + i) * n;
+  for (int v = lane; v < n; v += 64) dst[v] = src[v];
+}
+
+extern "C" void csgpu_search_free(csgpu_search *s) {
+  if (s == NULL) return;
+  (void)hipFree(s->pool); (void)hipFree(s->d_branch_var); (void)hipFree(s->d_child_count); (void)hipFree(s->d_child_off);
+  (void)hipFree(s->d_nodes); (void)hipFree(s->d_child_states); (void)hipFree(s->d_complete_states);
+  (void)hipFree(s->d_results); (void)hipFree(s->d_dest); (void)hipFree(s->d_complete_list); (void)hipFree(s->d_truth);
+  (void)hipFree(s->d_counters); (void)hipFree(s->d_best); (void)hipFree(s->d_solutions);
+  free(s);
+}
+
+extern "C" int csgpu_search_create(const csgpu_model *m, int64_t pool_capacity, int64_t max_children,
+                                   csgpu_search **out) {
+  if (m == NULL || out == NULL || pool_capacity < 1 || max_children < 1) return fail(CSGPU_E_ARG, "bad argument");
+  const int n = csgpu_model_num_vars(m);
+  if (n <= 0) return fail(CSGPU_E_ARG, "model without variables");
+  csgpu_search *s = (csgpu_search *)calloc(1, sizeof *s);
+  s->m = m;
+  s->n = n;
+  s->objective = csgpu_model_objective(m);
+  s->obj_var = csgpu_model_objective_var(m);
+  /* widest root interval bounds the branching factor (domains only shrink below the root) */
+  csgpu_val *dom = (csgpu_val *)malloc((size_t)n * sizeof *dom);
+  csgpu_model_get_domains(m, dom);
+  /* children of one parent: the interval's values if it has at most SPLIT_WIDTH of them, else 2.
+   * A wide root interval gets narrow by halving, so SPLIT_WIDTH bounds every variable that
+   * starts wider than that. */
+  s->max_width = 2;
+  for (int v = 0; v < n; v++) {
+    int64_t w = (int64_t)dom[v].hi - (int64_t)dom[v].lo + 1;
+    if (w > SPLIT_WIDTH) w = SPLIT_WIDTH;
+    if (w > s->max_width) s->max_width = w;
+  }
+  free(dom);
+  if (max_children < s->max_width) max_children = s->max_width;
+  if (max_children > 0x3fffffff) return fail(CSGPU_E_LIMIT, "max_children too large");
+  s->max_children = max_children;
+  s->max_parents = max_children / s->max_width;
+  if (pool_capacity < max_children + 1) pool_capacity = max_children + 1;
+  if (pool_capacity > 0x7fffffff) return fail(CSGPU_E_LIMIT, "pool_capacity too large");
+  s->cap = pool_capacity;
+  s->max_solutions = 1024;
+  s->st.best = s->objective == CS_OBJ_MIN ? CS_DOM_MAX : (s->objective == CS_OBJ_MAX ? CS_DOM_MIN : 0);
+  const size_t row = (size_t)n * sizeof(cs_val);
+  hipError_t e;
+#define ALLOC(ptr, bytes)                                                      \
+  if ((e = hipMalloc((void **)&(ptr), (bytes))) != hipSuccess) {               \
+    csgpu_search_free(s);                                                      \
+    return fail(CSGPU_E_HIP, hipGetErrorString(e));                            \
+  }
+  ALLOC(s->pool, row * (size_t)s->cap);
+  ALLOC(s->d_branch_var, sizeof(int) * (size_t)s->max_parents);
+  ALLOC(s->d_child_count, sizeof(int) * (size_t)s->max_parents);
+  ALLOC(s->d_child_off, sizeof(int) * ((size_t)s->max_parents + 1));
+  ALLOC(s->d_nodes, sizeof(csgpu_node) * (size_t)max_children);
+  ALLOC(s->d_child_states, row * (size_t)max_children);
+  ALLOC(s->d_complete_states, row * (size_t)max_children);
+  ALLOC(s->d_results, sizeof(csgpu_result) * (size_t)max_children);
+  ALLOC(s->d_dest, sizeof(int) * (size_t)max_children);
+  ALLOC(s->d_complete_list, sizeof(int) * (size_t)max_children);
+  ALLOC(s->d_truth, sizeof(int) * (size_t)max_children);
+  ALLOC(s->d_counters, sizeof(unsigned long long) * C_COUNT);
+  ALLOC(s->d_best, sizeof(int));
+  ALLOC(s->d_solutions, sizeof(int32_t) * (size_t)n * (size_t)s->max_solutions);
+#undef ALLOC
+  HIP_OK(hipMemset(s->d_counters, 0, sizeof(unsigned long long) * C_COUNT));
+  HIP_OK(hipMemcpy(s->d_best, &s->st.best, sizeof(int), hipMemcpyHostToDevice));
+  *out = s;
+  return CSGPU_OK;
+}
+
+extern "C" int csgpu_search_put(csgpu_search *s, const csgpu_val *d_states, int64_t count) {
+  if (s == NULL || (count > 0 && d_states == NULL) || count < 0) return fail(CSGPU_E_ARG, "bad argument");
+  if (s->top + count > s->cap) return fail(CSGPU_E_LIMIT, "state pool is full");
+  if (count > 0)
+    HIP_OK(hipMemcpy(s->pool + (size_t)s->top * s->n, d_states, (size_t)count * s->n * sizeof(cs_val),
+                     hipMemcpyDeviceToDevice));
+  s->top += count;
+  if (s->top > s->peak) s->peak = s->top;
+  return CSGPU_OK;
+}
+
+extern "C" int csgpu_search_take(csgpu_search *s, csgpu_val *d_states, int64_t max, int64_t *count) {
+  if (s == NULL || d_states == NULL || count == NULL || max < 0) return fail(CSGPU_E_ARG, "bad argument");
+  int64_t k = max < s->top ? max : s->top;
+  *count = k;
+  if (k == 0) return CSGPU_OK;
+  HIP_OK(hipMemcpy(d_states, s->pool, (size_t)k * s->n * sizeof(cs_val), hipMemcpyDeviceToDevice));
+  /* fill the hole at the bottom with the newest rows */
+  const int64_t rest = s->top - k, mv = rest < k ? rest : k;
+  if (mv > 0) {
+    hipLaunchKernelGGL(cs_move_rows, dim3((unsigned)((mv + 3) / 4)), dim3(SB), 0, 0, s->pool, (long long)(s->top - mv),
+                       0ll, (int)mv, s->n);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipDeviceSynchronize());
+  }
+  s->top -= k;
+  return CSGPU_OK;
+}
+
+extern "C" int csgpu_search_set_best(csgpu_search *s, int32_t best) {
+  if (s == NULL) return fail(CSGPU_E_ARG, "bad argument");
+  int better = (s->objective == CS_OBJ_MIN && best < s->st.best) || (s->objective == CS_OBJ_MAX && best > s->st.best);
+  if (better) {
+    s->st.best = best;
+    HIP_OK(hipMemcpy(s->d_best, &best, sizeof(int), hipMemcpyHostToDevice));
+  }
+  return CSGPU_OK;
+}
+
+static int one_iteration(csgpu_search *s) {
+  const int n = s->n;
+  int64_t parents = s->top < s->max_parents ? s->top : s->max_parents;
+  /* survivors go back above the consumed parents: guaranteed room for max_children rows */
+  if (s->top - parents + s->max_children > s->cap) {
+    parents = s->top < 1 ? 0 : 1; /* a nearly full pool: fall back to strict depth-first */
+    if (s->top - parents + s->max_width > s->cap) return fail(CSGPU_E_LIMIT, "state pool is full");
+  }
+  const long long first_row = s->top - parents;
+  if (parents == 0) return CSGPU_OK;
+  HIP_OK(hipMemsetAsync(s->d_counters, 0, sizeof(unsigned long long) * C_STORED, 0));
+  const unsigned pb = (unsigned)((parents + 3) / 4);
+  hipLaunchKernelGGL(cs_branch, dim3(pb), dim3(SB), 0, 0, s->pool, first_row, (int)parents, n, s->d_branch_var,
+                     s->d_child_count);
+  hipLaunchKernelGGL(cs_scan, dim3(1), dim3(1024), 0, 0, s->d_child_count, (int)parents, s->d_child_off, s->d_counters);
+  unsigned long long total = 0;
+  HIP_OK(hipMemcpy(&total, s->d_counters + C_TOTAL_CHILDREN, sizeof total, hipMemcpyDeviceToHost));
+  const int64_t children = (int64_t)total;
+  if (children > s->max_children) return fail(CSGPU_E_LIMIT, "internal: more children than the batch buffers hold");
+  hipLaunchKernelGGL(cs_emit, dim3(pb), dim3(SB), 0, 0, s->pool, first_row, (int)parents, n, s->d_branch_var,
+                     s->d_child_off, s->d_nodes, s->objective == CS_OBJ_MAX ? 0 : 1);
+  s->top -= parents;
+  s->st.iterations++;
+  if (children == 0) return CSGPU_OK;
+
+  /* the incumbent tightens "<obj>" for every child (objective.c:101-126) */
+  int32_t obj_lo = CS_DOM_MIN, obj_hi = CS_DOM_MAX;
+  if (s->objective == CS_OBJ_MIN) obj_hi = cs_add(s->st.best, cs_neg(1));
+  if (s->objective == CS_OBJ_MAX) obj_lo = cs_add(s->st.best, 1);
+  int rc = csgpu_propagate_batch_obj(s->m, (const csgpu_val *)s->pool, s->d_nodes, (csgpu_val *)s->d_child_states,
+                                     s->d_results, children, obj_lo, obj_hi, NULL);
+  if (rc != CSGPU_OK) return rc;
+  const unsigned cb = (unsigned)((children + SB - 1) / SB), cw = (unsigned)((children + 3) / 4);
+  hipLaunchKernelGGL(cs_select, dim3(cb), dim3(SB), 0, 0, s->d_results, (int)children, (long long)s->top, s->d_dest,
+                     s->d_complete_list, s->d_counters);
+  hipLaunchKernelGGL(cs_scatter, dim3(cw), dim3(SB), 0, 0, s->d_child_states, s->d_dest, (int)children, n, s->pool);
+  unsigned long long c[C_COUNT];
+  HIP_OK(hipMemcpy(c, s->d_counters, sizeof c, hipMemcpyDeviceToHost));
+  s->top += (int64_t)c[C_SURVIVORS];
+  if (s->top > s->peak) s->peak = s->top;
+  s->st.nodes += (uint64_t)children;
+  s->st.cuts += c[C_CUTS];
+  s->st.props += c[C_PROPS];
+  s->st.revisions += c[C_REVS];
+
+  const int64_t complete = (int64_t)c[C_COMPLETE];
+  if (complete > 0) {
+    const unsigned gw = (unsigned)((complete + 3) / 4);
+    hipLaunchKernelGGL(cs_gather_complete, dim3(gw), dim3(SB), 0, 0, s->d_child_states, s->d_complete_list,
+                       (int)complete, n, s->d_complete_states);
+    rc = csgpu_eval_batch(s->m, (const csgpu_val *)s->d_complete_states, s->d_truth, complete, NULL);
+    if (rc != CSGPU_OK) return rc;
+    hipLaunchKernelGGL(cs_accept, dim3(gw), dim3(SB), 0, 0, s->d_complete_states, s->d_truth, (int)complete, n,
+                       s->objective, s->obj_var, s->d_best, s->d_counters, s->d_solutions,
+                       (long long)s->max_solutions);
+    unsigned long long sol = 0;
+    int best = 0;
+    HIP_OK(hipMemcpy(&sol, s->d_counters + C_SOLUTIONS, sizeof sol, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(&best, s->d_best, sizeof best, hipMemcpyDeviceToHost));
+    s->st.solutions += sol;
+    s->st.best = best;
+  }
+  HIP_OK(hipGetLastError());
+  return CSGPU_OK;
+}
+
+extern "C" int csgpu_search_run(csgpu_search *s, int64_t max_iterations, csgpu_search_stats *stats) {
+  if (s == NULL || stats == NULL) return fail(CSGPU_E_ARG, "bad argument");
+  for (int64_t it = 0; it < max_iterations; it++) {
+    if (s->top == 0) break;
+    if (s->objective == CS_OBJ_ANY && s->st.solutions > 0) break;
+    int rc = one_iteration(s);
+    if (rc != CSGPU_OK) return rc;
+  }
+  s->st.pool = s->top;
+  s->st.pool_peak = s->peak;
+  s->st.done = s->top == 0 || (s->objective == CS_OBJ_ANY && s->st.solutions > 0);
+  *stats = s->st;
+  return CSGPU_OK;
+}
+
+extern "C" int64_t csgpu_search_solutions(const csgpu_search *s, int32_t *values, int64_t max) {
+  if (s == NULL || values == NULL || max < 0) return CSGPU_E_ARG;
+  unsigned long long stored = 0;
+  if (hipMemcpy(&stored, s->d_counters + C_STORED, sizeof stored, hipMemcpyDeviceToHost) != hipSuccess) return CSGPU_E_HIP;
+  int64_t k = (int64_t)stored;
+  if (k > s->max_solutions) k = s->max_solutions;
+  if (k > max) k = max;
+  if (k > 0 && hipMemcpy(values, s->d_solutions, (size_t)k * s->n * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess)
+    return CSGPU_E_HIP;
+  return k;
+}

@@ -1,0 +1,163 @@
+"""Subtree sharding of the search across ranks (one process per GPU, torch.distributed).
+
+Reference mechanism being replaced: `worker_spawn` forks a child that takes the
+upper half of the branching variable's interval whenever a worker slot is free
+(reference src/csolve.c:105-152), all workers share one page holding the incumbent objective
+value, the solution count and the timeout flag (csolve.c:86-97, objective.c:89-93,135).
+HIP state does not survive fork(), so ranks exist up front and exchange
+  * open states (whole subtrees) taken from the OLDEST end of a rank's pool -- work stealing,
+  * the incumbent bound (min / max over ranks) and the found-a-solution / pool-size words.
+Over RCCL (backend "nccl") the exchanged tensors stay in device memory and travel over xGMI;
+the same code runs over gloo with host tensors (CPU tests, or several ranks sharing one GPU).
+
+Propagation of a single node is never split across ranks: the data path has no collective.
+"""
+from __future__ import annotations
+
+import torch
+
+OBJ_ANY, OBJ_ALL, OBJ_MIN, OBJ_MAX = 0, 1, 2, 3
+INT32_MAX, INT32_MIN = 2**31 - 1, -(2**31)
+
+
+def plan_transfers(pools, low_water: int):
+    """Deterministic rebalancing plan from the gathered pool sizes: pair the richest rank with
+    the poorest while the poorest is below `low_water` and the richest can spare states.
+    -> list of (src, dst, count).  Every rank computes the same plan."""
+    pools = list(pools)
+    plan = []
+    order = sorted(range(len(pools)), key=lambda r: (pools[r], r))
+    lo, hi = 0, len(order) - 1
+    while lo < hi:
+        poor, rich = order[lo], order[hi]
+        if pools[poor] >= low_water:
+            break
+        give = (pools[rich] - pools[poor]) // 2
+        if give <= 0:
+            break
+        plan.append((rich, poor, give))
+        pools[rich] -= give
+        pools[poor] += give
+        lo += 1
+        hi -= 1
+    return plan
+
+
+class ShardedSearch:
+    """Runs one search engine per rank and keeps them busy.
+
+    engine: object with put(states), take(k) -> states, run(iterations) -> stats dict,
+            set_best(value); states are int32 tensors [k, n_vars, 2] on `engine_device`.
+    comm_device: device of the tensors handed to torch.distributed ("cuda" for nccl/RCCL,
+            "cpu" for gloo).
+    """
+
+    def __init__(self, engine, objective: int, n_vars: int, rank: int, world: int, dist=None,
+                 engine_device="cuda", comm_device=None, slice_iterations: int = 64, seed_states_per_rank: int = 64,
+                 low_water: int = 64):
+        self.engine, self.objective, self.n, self.rank, self.world = engine, objective, n_vars, rank, world
+        self.dist = dist
+        self.engine_device = engine_device
+        self.comm_device = comm_device or engine_device
+        self.slice_iterations = slice_iterations
+        self.seed_states_per_rank = seed_states_per_rank
+        self.low_water = low_water
+        self.exchanges = 0
+        self.states_moved = 0
+
+    # ---- helpers ---------------------------------------------------------------------------
+    def _to_comm(self, t):
+        return t.to(self.comm_device).contiguous()
+
+    def _to_engine(self, t):
+        return t.to(self.engine_device).contiguous()
+
+    def _gather_words(self, words):
+        """all_gather of a few int64 words per rank -> [world, len(words)] (host list)"""
+        mine = torch.tensor(words, dtype=torch.int64, device=self.comm_device)
+        if self.dist is None or self.world == 1:
+            return [list(words)]
+        out = torch.empty(self.world * len(words), dtype=torch.int64, device=self.comm_device)
+        self.dist.all_gather_into_tensor(out, mine)
+        return out.view(self.world, len(words)).cpu().tolist()
+
+    # ---- phases ----------------------------------------------------------------------------
+    def seed(self, root_state):
+        """Rank 0 expands the root until there are enough open states, then deals them out
+        round-robin (the analogue of the reference's repeated interval halving)."""
+        stats = None
+        if self.world == 1:
+            self.engine.put(root_state)
+            return
+        frontier = None
+        if self.rank == 0:
+            self.engine.put(root_state)
+            want = self.seed_states_per_rank * self.world
+            stats = self.engine.run(1)
+            while not stats["done"] and stats["pool"] < want:
+                stats = self.engine.run(1)
+            frontier = self._to_comm(self.engine.take(stats["pool"]))
+        count = torch.tensor([0 if frontier is None else frontier.shape[0]], dtype=torch.int64, device=self.comm_device)
+        self.dist.broadcast(count, src=0)
+        k = int(count.item())
+        if k == 0:
+            return
+        if frontier is None:
+            frontier = torch.empty((k, self.n, 2), dtype=torch.int32, device=self.comm_device)
+        self.dist.broadcast(frontier, src=0)
+        mine = frontier[self.rank::self.world]
+        if mine.shape[0] > 0:
+            self.engine.put(self._to_engine(mine))
+
+    def _exchange(self, stats):
+        """incumbent, termination and work stealing; returns True when the search is over"""
+        found = 1 if stats["solutions"] > 0 else 0
+        table = self._gather_words([stats["pool"], stats["best"], found])
+        pools = [int(r[0]) for r in table]
+        if self.objective == OBJ_MIN:
+            self.engine.set_best(min(int(r[1]) for r in table))
+        elif self.objective == OBJ_MAX:
+            self.engine.set_best(max(int(r[1]) for r in table))
+        if self.objective == OBJ_ANY and any(int(r[2]) for r in table):
+            return True
+        if sum(pools) == 0:
+            return True
+        for src, dst, cnt in plan_transfers(pools, self.low_water):
+            self.exchanges += 1
+            if self.rank == src:
+                states = self._to_comm(self.engine.take(cnt))
+                assert states.shape[0] == cnt
+                self.dist.send(states, dst=dst)
+                self.states_moved += cnt
+            elif self.rank == dst:
+                buf = torch.empty((cnt, self.n, 2), dtype=torch.int32, device=self.comm_device)
+                self.dist.recv(buf, src=src)
+                self.engine.put(self._to_engine(buf))
+        return False
+
+    def run(self, root_state, max_slices: int = 1 << 40):
+        """-> (local stats dict, global totals dict)"""
+        self.seed(root_state)
+        stats = self.engine.run(0)
+        for _ in range(max_slices):
+            stats = self.engine.run(self.slice_iterations)
+            if self.world == 1:
+                if stats["done"]:
+                    break
+                continue
+            if self._exchange(stats):
+                break
+        totals = dict(stats)
+        if self.dist is not None and self.world > 1:
+            keys = ("nodes", "cuts", "props", "revisions", "solutions", "iterations")
+            t = torch.tensor([stats[k] for k in keys], dtype=torch.int64, device=self.comm_device)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+            for k, v in zip(keys, t.cpu().tolist()):
+                totals[k] = int(v)
+            b = torch.tensor([stats["best"]], dtype=torch.int64, device=self.comm_device)
+            if self.objective == OBJ_MIN:
+                self.dist.all_reduce(b, op=self.dist.ReduceOp.MIN)
+            elif self.objective == OBJ_MAX:
+                self.dist.all_reduce(b, op=self.dist.ReduceOp.MAX)
+            totals["best"] = int(b.item())
+        return stats, totals

@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 import torch
 
-from ._lib import Node, Result, Val, check, load_library
+from ._lib import Node, Result, SearchStats, Val, check, load_library
 
 STATUS_FAIL = -1
 
@@ -174,6 +174,56 @@ class Model:
         check(load_library().csgpu_propagate_one(self._h, state.ctypes.data, Node(var, lo, hi, 0),
                                                  out.ctypes.data, C.byref(res)))
         return res.status, res.props, out
+
+
+class Search:
+    """Device-resident tree search over a finalized model (csgpu_search_*): a LIFO pool of open
+    states in HBM, expanded and propagated in batches.  One instance per GPU/rank."""
+
+    def __init__(self, model: Model, pool_capacity: int = 1 << 20, max_children: int = 1 << 16):
+        self.model = model
+        self._h = C.c_void_p()
+        check(load_library().csgpu_search_create(model._h, pool_capacity, max_children, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            load_library().csgpu_search_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def put(self, states: torch.Tensor):
+        """append open states [k, n_vars, 2] (device) to the pool"""
+        if states.numel() == 0:
+            return
+        assert states.is_cuda and states.dtype == torch.int32 and states.is_contiguous()
+        assert states.shape[-2:] == (self.model.n_vars, 2)
+        check(load_library().csgpu_search_put(self._h, states.data_ptr(), states.shape[0]))
+
+    def take(self, max_states: int) -> torch.Tensor:
+        """remove up to max_states of the oldest open states (largest subtrees)"""
+        buf = torch.empty((max(1, max_states), self.model.n_vars, 2), dtype=torch.int32, device="cuda")
+        cnt = C.c_int64()
+        check(load_library().csgpu_search_take(self._h, buf.data_ptr(), max_states, C.byref(cnt)))
+        return buf[: cnt.value]
+
+    def set_best(self, best: int):
+        check(load_library().csgpu_search_set_best(self._h, int(best)))
+
+    def run(self, max_iterations: int = 1 << 62) -> dict:
+        st = SearchStats()
+        check(load_library().csgpu_search_run(self._h, max_iterations, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in SearchStats._fields_}
+
+    def solutions(self, max_solutions: int = 1024) -> np.ndarray:
+        out = np.empty((max(1, max_solutions), self.model.n_vars), dtype=np.int32)
+        k = load_library().csgpu_search_solutions(self._h, out.ctypes.data, max_solutions)
+        check(k)
+        return out[:k]
 
 
 def solve_root(text: str, weights_on: bool = True) -> Model:

@@ -58,7 +58,8 @@ typedef struct csgpu_node {
   int32_t var, lo, hi, parent;
 } csgpu_node;
 
-/* per-node result.  status: -1 = PROP_ERROR (csolve.h:84), 0 = consistent.
+/* per-node result.  status: -1 = PROP_ERROR (csolve.h:84); otherwise the node is consistent and
+ * status = number of variables that are still open (not a single value), 0 = complete assignment.
  * props = narrowing events (the reference's PROPS counter, propagate.c:77-78),
  * revisions = clause revisions performed, rounds = worklist rounds. */
 typedef struct csgpu_result {
@@ -120,6 +121,14 @@ int csgpu_model_finalize(csgpu_model *m);
 int csgpu_propagate_batch(const csgpu_model *m, const csgpu_val *d_states_in, const csgpu_node *d_nodes,
                           csgpu_val *d_states_out, csgpu_result *d_results, int64_t batch, void *stream);
 
+/* Same, with the incumbent bound of an optimisation run: before a node is propagated the
+ * objective variable "<obj>" is intersected with [obj_lo, obj_hi] (objective_update_val,
+ * objective.c:101-126) and, if that moved a bound, its clauses are propagated as well
+ * (check_assignment, csolve.c:251-252).  Pass INT32_MIN / INT32_MAX for "no bound". */
+int csgpu_propagate_batch_obj(const csgpu_model *m, const csgpu_val *d_states_in, const csgpu_node *d_nodes,
+                              csgpu_val *d_states_out, csgpu_result *d_results, int64_t batch, int32_t obj_lo,
+                              int32_t obj_hi, void *stream);
+
 /* Three-valued evaluation of the root wide-and for a batch of states:
  * d_truth[i] = 1 (all clauses true), 0 (some clause false), 2 (undecided). */
 int csgpu_eval_batch(const csgpu_model *m, const csgpu_val *d_states, int32_t *d_truth, int64_t batch,
@@ -129,6 +138,46 @@ int csgpu_eval_batch(const csgpu_model *m, const csgpu_val *d_states, int32_t *d
  * entry points of the reference (eval.c:27-255) applied to each clause root.
  * d_vals: device, [n_clauses] csgpu_val. */
 int csgpu_eval_clauses(const csgpu_model *m, const csgpu_val *d_state, csgpu_val *d_vals, void *stream);
+
+/* ---- device-resident tree search (the batched analogue of solve(), csolve.c:398-476) ----
+ *
+ * A LIFO pool of open states lives in HBM.  One iteration pops the newest states, branches each
+ * on its first open variable (every value of its interval becomes a child, as step_val
+ * enumerates them, csolve.c:331-338), propagates all children in one csgpu_propagate_batch_obj
+ * launch, counts the inconsistent ones as cuts, checks complete assignments with the root
+ * evaluation (update_solution, csolve.c:222-244) and pushes the open survivors back.
+ * The search tree is the reference's (same children, same propagation per child); the ORDER in
+ * which it is walked is not, so CALLS/CUTS are engine-specific while the set of solutions and
+ * the optimum are not.  Subtree sharding across GPUs moves whole states between the pools of
+ * different ranks (csgpu_search_take / _put) and exchanges the incumbent (_set_best). */
+typedef struct csgpu_search csgpu_search;
+
+typedef struct csgpu_search_stats {
+  uint64_t nodes;      /* children propagated = CALLS */
+  uint64_t cuts;       /* inconsistent children = CUTS */
+  uint64_t props;      /* narrowing events = PROPS */
+  uint64_t revisions;  /* clause revisions */
+  uint64_t solutions;  /* accepted solutions (root evaluates to true) */
+  uint64_t iterations; /* batched expand+propagate rounds */
+  int64_t pool;        /* open states now in the pool */
+  int64_t pool_peak;
+  int32_t best;        /* incumbent (MIN/MAX), INT32_MAX / INT32_MIN if none yet */
+  int32_t done;        /* 1: pool empty, or objective ANY and a solution was found */
+} csgpu_search_stats;
+
+/* pool_capacity: states the pool can hold; max_children: children propagated per iteration */
+int csgpu_search_create(const csgpu_model *m, int64_t pool_capacity, int64_t max_children, csgpu_search **out);
+void csgpu_search_free(csgpu_search *s);
+/* append `count` states ([count][n_vars], device memory) to the pool */
+int csgpu_search_put(csgpu_search *s, const csgpu_val *d_states, int64_t count);
+/* remove up to `max` of the OLDEST states (the largest subtrees) into d_states; *count = how many */
+int csgpu_search_take(csgpu_search *s, csgpu_val *d_states, int64_t max, int64_t *count);
+/* merge an incumbent found elsewhere (objective_best of the shared page, objective.c:89-93) */
+int csgpu_search_set_best(csgpu_search *s, int32_t best);
+/* run up to max_iterations iterations (stops early when done) */
+int csgpu_search_run(csgpu_search *s, int64_t max_iterations, csgpu_search_stats *stats);
+/* copy up to `max` stored solutions ([k][n_vars] values, host memory); returns k */
+int64_t csgpu_search_solutions(const csgpu_search *s, int32_t *values, int64_t max);
 
 /* Convenience for single nodes with host buffers (used by the drop-in shim):
  * uploads `state` (n_vars), runs one node, downloads the result.  Synchronous. */

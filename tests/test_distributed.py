@@ -1,0 +1,96 @@
+"""CPU tests (gloo, world_size 2 and 3) of the multi-rank search coordinator: seeding from rank 0,
+work stealing of open states, incumbent exchange, termination.  The engines are the oracle-backed
+CPU stand-in (tests/cpu_engine.py); the coordinator code is exactly what runs over RCCL."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import ROOT, golden
+
+
+def test_transfer_plan_is_deterministic_and_conserving():
+    from csolve_amd.parallel import plan_transfers
+    plan = plan_transfers([0, 1000, 10, 400], low_water=64)
+    assert plan == [(1, 0, 500), (3, 2, 195)]
+    pools = [0, 1000, 10, 400]
+    for s, d, c in plan:
+        pools[s] -= c
+        pools[d] += c
+    assert sum(pools) == 1410 and min(pools) >= 64
+    assert plan_transfers([100, 100], 64) == [] and plan_transfers([0, 1], 64) == []
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, text, out_q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from cpu_engine import OracleEngine
+    from csolve_amd.parallel import ShardedSearch
+    from oracle.cs_oracle import Model as OModel, Oracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    om = OModel.parse(text)
+    o0 = Oracle(om)
+    o0.set_root_phase(True)
+    assert o0.propagate(om.root, om.n_vars) >= 0
+    om.set_domains(o0.domains())
+    om.index()
+    eng = OracleEngine(om)
+    sh = ShardedSearch(eng, om.view.objective, om.n_vars, rank, world, dist, engine_device="cpu",
+                       slice_iterations=8, seed_states_per_rank=4, low_water=4)
+    root = torch.from_numpy(om.domains()).unsqueeze(0).contiguous()
+    local, totals = sh.run(root)
+    out_q.put((rank, local["nodes"], local["solutions"], totals["nodes"], totals["solutions"], totals["best"],
+               sh.states_moved))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(world, text):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, text, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = sorted(q.get(timeout=150) for _ in range(world))
+    finally:
+        for p in procs:
+            p.join(timeout=20)
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs)
+    return res
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_all_solutions(world):
+    """queens-8 ALL over 2 and 3 ranks: 92 solutions in total, every rank does part of the work,
+    and the total number of explored nodes equals the single-engine tree."""
+    from csolve_amd import problems
+    res = _run(world, problems.queens(8, "ALL"))
+    assert all(r[4] == 92 for r in res)
+    assert sum(r[2] for r in res) == 92
+    assert all(r[1] > 0 for r in res), "a rank stayed idle"
+    single = _run(1, problems.queens(8, "ALL"))
+    assert res[0][3] == single[0][3]
+
+
+def test_sharded_minimisation_shares_the_incumbent():
+    """schedule-6 MIN over 2 ranks: optimum 22 (reference golden), known to every rank."""
+    res = _run(2, open(golden("problems", "schedule6_s1.txt")).read())
+    assert all(r[5] == 22 for r in res)

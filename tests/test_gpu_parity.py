@@ -143,6 +143,7 @@ def test_batch_vs_oracle_and_properties(kind, size):
         parent = states[nodes[:, 3]]
         assert (out_h[ok, :, 0] >= parent[ok, :, 0]).all() and (out_h[ok, :, 1] <= parent[ok, :, 1]).all()
         assert (out_h[ok, :, 0] <= out_h[ok, :, 1]).all()
+        assert (res_h[ok, 0] == (out_h[ok, :, 0] != out_h[ok, :, 1]).sum(1)).all()  # status = open variables
         idx = np.nonzero(ok)[0]
         assert (out_h[idx, nodes[idx, 0], 0] == nodes[idx, 1]).all()
         # fixpoint: full re-propagation changes nothing
@@ -151,7 +152,7 @@ def test_batch_vs_oracle_and_properties(kind, size):
         sub = out[torch.from_numpy(idx).cuda()].contiguous()
         out2, res2 = model.propagate(sub, torch.from_numpy(again_nodes).cuda())
         torch.cuda.synchronize()
-        assert (res2[:, 0] == 0).all() and (res2[:, 1] == 0).all()
+        assert (res2[:, 0] >= 0).all() and (res2[:, 1] == 0).all()
         assert torch.equal(out2, sub)
         # splitting the batch does not change anything
         half = count // 2
@@ -194,4 +195,5 @@ def test_propagate_one_host_path():
         if walk["status"][i] < 0:
             assert st == -1
         else:
-            assert st == 0 and props == walk["status"][i] and (out == walk["after"][i]).all()
+            assert st == int((out[:, 0] != out[:, 1]).sum()) and props == walk["status"][i]
+            assert (out == walk["after"][i]).all()

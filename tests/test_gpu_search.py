@@ -1,0 +1,102 @@
+"""GPU tests of the device-resident search engine: solution counts, optima and solution
+validity against the goldens of the compiled reference (tests/golden/solve_stats.json) and
+the oracle."""
+import json
+
+import numpy as np
+import pytest
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _solve(text, pool=1 << 18, children=1 << 14, iters=1 << 40):
+    from csolve_amd.solver import Search, solve_root
+    model = solve_root(text)
+    s = Search(model, pool, children)
+    s.put(model.root_state())
+    st = s.run(iters)
+    return model, s, st
+
+
+@pytest.mark.parametrize("n,count", [(4, 2), (6, 4), (8, 92), (10, 724), (12, 14200)])
+def test_all_solutions_of_queens(n, count):
+    """queens-8/10/12 ALL: 92 / 724 / 14,200 solutions (the reference's own counts)."""
+    from csolve_amd import problems
+    model, s, st = _solve(problems.queens(n, "ALL"))
+    assert st["done"] == 1 and st["pool"] == 0
+    assert st["solutions"] == count
+    assert st["nodes"] - st["cuts"] >= st["solutions"]
+    sols = s.solutions(1024)
+    assert len(sols) == min(count, 1024)
+    # every stored solution is a valid placement
+    for row in sols[:200]:
+        assert len(set(row)) == n and len(set(row + np.arange(n))) == n and len(set(row - np.arange(n))) == n
+
+
+def test_any_stops_at_first_solution():
+    from csolve_amd import problems
+    model, s, st = _solve(problems.queens(16))
+    assert st["done"] == 1 and st["solutions"] >= 1
+    row = s.solutions(1)[0]
+    assert len(set(row)) == 16 and len(set(row + np.arange(16))) == 16 and len(set(row - np.arange(16))) == 16
+
+
+@pytest.mark.parametrize("name,best", [("ref_schedule", 11), ("schedule6_s1", 22), ("ref_wcet", 1560)])
+def test_optimisation_reaches_the_reference_optimum(name, best):
+    """MIN / MAX with the incumbent bound pushed into every batch: examples/schedule.txt -> 11,
+    schedule-6 -> 22, examples/wcet.txt -> 1560 (reference goldens)."""
+    model, s, st = _solve(open(golden("problems", name + ".txt")).read(), pool=1 << 20, children=1 << 16)
+    assert st["done"] == 1
+    assert st["best"] == best
+    assert st["solutions"] >= 1
+
+
+def test_search_counters_match_oracle_tree_on_all():
+    """For ALL the set of explored nodes does not depend on the walking order as long as the
+    branching variable of a state is a function of the state: compare CALLS/CUTS/solutions with a
+    plain CPU walk of the same tree that uses the oracle for every child."""
+    from csolve_amd import problems
+    from oracle.cs_oracle import Model as OModel, Oracle
+    text = problems.queens(7, "ALL")
+    model, s, st = _solve(text)
+    om = OModel.parse(text)
+    om.set_domains(model.domains())
+    om.index()
+    orc = Oracle(om)
+    calls = cuts = sols = 0
+    stack = [model.domains()]
+    while stack:
+        state = stack.pop()
+        width = (state[:, 1] - state[:, 0]).astype(np.int64)
+        width[width == 0] = 1 << 40
+        v = int(np.argmin(width))  # smallest open interval, ties -> lowest index (cs_branch)
+        for val in range(state[v, 0], state[v, 1] + 1):
+            calls += 1
+            status, out = orc.instance(state, v, val, val)
+            if status < 0:
+                cuts += 1
+            elif (out[:, 0] == out[:, 1]).all():
+                sols += 1
+            else:
+                stack.append(out)
+    assert (st["nodes"], st["cuts"], st["solutions"]) == (calls, cuts, sols)
+
+
+def test_take_and_put_move_subtrees_between_engines():
+    """Work stealing primitive: states taken from one pool and put into another are explored
+    there; the two engines together find every solution exactly once."""
+    from csolve_amd import problems
+    from csolve_amd.solver import Search, solve_root
+    model = solve_root(problems.queens(9, "ALL"))
+    a, b = Search(model, 1 << 16, 1 << 12), Search(model, 1 << 16, 1 << 12)
+    a.put(model.root_state())
+    a.run(3)
+    stolen = a.take(10)
+    assert 0 < stolen.shape[0] <= 10
+    b.put(stolen.contiguous())
+    sa, sb = a.run(), b.run()
+    assert sa["done"] and sb["done"]
+    assert sa["solutions"] + sb["solutions"] == 352

@@ -218,6 +218,7 @@ def main():
     ap.add_argument("--instances", type=int, default=1 << 18, help="node instances per GPU")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 general, 2 LDS-resident")
     ap.add_argument("--workload", choices=["propagate", "search"], default="propagate")
     ap.add_argument("--search-queens", type=int, default=13)
     ap.add_argument("--pool", type=int, default=1 << 21)
@@ -251,6 +252,8 @@ def main():
     n_q = args.queens
     text = problems.queens(n_q)
     model = solve_root(text)
+    model.set_kernel(args.kernel)
+    kernel_name = {1: "cs_propagate_events", 2: "cs_propagate_ne_lds"}[model.kernel()]
     n = model.n_vars
     info = model.device_info()
 
@@ -315,7 +318,7 @@ def main():
                    "props_per_node": props_all / nodes_all, "revisions_per_node": revs_all / nodes_all},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "cs_propagate_events<false>", "kernel_ms": kernel_ms,
+                     "kernel": kernel_name, "kernel_ms": kernel_ms,
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "hbm_stream_bytes_per_launch": stream_bytes,
                      "hbm_stream_frac": stream_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},

@@ -43,6 +43,10 @@ struct csgpu_model {
   cs_tables tab;
   size_t slice;      /* LDS bytes per node instance (16-byte aligned) */
   int has_tree_adj;  /* some adjacency entry is a tree clause */
+  int kernel_choice; /* 0 auto, 1 general, 2 LDS-resident */
+  void *d_adj_packed;
+  int lds_waves;     /* waves per workgroup of the LDS-resident kernel, 0 = not eligible */
+  size_t lds_bytes;  /* its dynamic LDS size */
   int n_cus;
   /* staging of csgpu_propagate_one */
   cs_val *d_one_in, *d_one_out;
@@ -126,6 +130,9 @@ static void free_device(csgpu_model *m) {
   (void)hipFree(m->d_adj_off); (void)hipFree(m->d_adj); (void)hipFree(m->d_clause);
   (void)hipFree(m->d_tree_off); (void)hipFree(m->d_tnode); (void)hipFree(m->d_tkid); (void)hipFree(m->d_tree_want);
   m->d_tree_want = NULL;
+  (void)hipFree(m->d_adj_packed);
+  m->d_adj_packed = NULL;
+  m->lds_waves = 0;
   (void)hipFree(m->d_one_in); (void)hipFree(m->d_one_out); (void)hipFree(m->d_one_node); (void)hipFree(m->d_one_res);
   m->d_adj_off = m->d_adj = m->d_clause = m->d_tree_off = m->d_tnode = m->d_tkid = NULL;
   m->d_one_in = m->d_one_out = NULL;
@@ -392,6 +399,29 @@ extern "C" int csgpu_model_finalize(csgpu_model *m) {
   if ((rc = lds_limit((size_t)h->n_vars * sizeof(cs_val) + 16, (const void *)cs_eval_root))) return rc;
   if ((rc = lds_limit((size_t)h->n_vars * sizeof(cs_val) + 16, (const void *)cs_eval_clauses))) return rc;
 
+  /* LDS-resident kernel: adj_off + packed adjacency + one slice per wave must fit in a CU's LDS */
+  m->lds_waves = 0;
+  if (m->img->packed_width != 0) {
+    const size_t off_bytes = (((size_t)(h->n_vars + 1) * sizeof(int)) + 15) & ~(size_t)15;
+    const size_t adj_bytes = (((size_t)m->img->n_adj * (size_t)m->img->packed_width) + 15) & ~(size_t)15;
+    for (int waves = 16; waves >= 4; waves >>= 1) {
+      const size_t need = off_bytes + adj_bytes + (size_t)waves * m->slice;
+      if (need <= 160u * 1024u) {
+        m->lds_waves = waves;
+        m->lds_bytes = need;
+        break;
+      }
+    }
+    if (m->lds_waves) {
+      if ((rc = upload(m->img->adj_packed, (size_t)m->img->n_adj * (size_t)m->img->packed_width,
+                       (int **)&m->d_adj_packed)))
+        return rc;
+      const void *fn = m->img->packed_width == 2 ? (const void *)cs_propagate_ne_lds<unsigned short>
+                                                 : (const void *)cs_propagate_ne_lds<unsigned int>;
+      if ((rc = lds_limit(m->lds_bytes, fn))) return rc;
+    }
+  }
+
   int dev = 0;
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDevice(&dev));
@@ -405,6 +435,22 @@ extern "C" int csgpu_model_finalize(csgpu_model *m) {
   HIP_TRY(hipMalloc((void **)&m->d_one_res, sizeof(cs_node_out)));
   m->finalized = 1;
   return CSGPU_OK;
+}
+
+extern "C" int csgpu_model_set_kernel(csgpu_model *m, int which) {
+  if (m == NULL || which < 0 || which > 2) return set_err(CSGPU_E_ARG, "bad argument");
+  if (which == 2) {
+    if (!m->finalized) return set_err(CSGPU_E_STATE, "model is not finalized");
+    if (!m->lds_waves) return set_err(CSGPU_E_LIMIT, "model does not qualify for the LDS-resident kernel");
+  }
+  m->kernel_choice = which;
+  return CSGPU_OK;
+}
+
+extern "C" int csgpu_model_get_kernel(const csgpu_model *m) {
+  if (m == NULL) return CSGPU_E_ARG;
+  if (m->kernel_choice) return m->kernel_choice;
+  return m->lds_waves ? 2 : 1;
 }
 
 /* ---- batched propagation ----------------------------------------------------------- */
@@ -441,6 +487,26 @@ extern "C" int csgpu_propagate_batch_obj(const csgpu_model *m, const csgpu_val *
     tab.obj_var = m->host->obj_var;
     tab.obj_lo = obj_lo;
     tab.obj_hi = obj_hi;
+  }
+  if (csgpu_model_get_kernel(m) == 2 && tab.obj_var < 0) {
+    /* persistent workgroups: as many as stay resident (LDS- and wave-slot-limited) */
+    size_t wg_per_cu = (160u * 1024u) / m->lds_bytes;
+    if (wg_per_cu > (size_t)(32 / m->lds_waves)) wg_per_cu = (size_t)(32 / m->lds_waves);
+    if (wg_per_cu < 1) wg_per_cu = 1;
+    int64_t grid = (int64_t)m->n_cus * (int64_t)wg_per_cu;
+    const int64_t need = (batch + m->lds_waves - 1) / m->lds_waves;
+    if (grid > need) grid = need;
+    const dim3 blk((unsigned)(m->lds_waves * CS_WAVE));
+    if (m->img->packed_width == 2)
+      hipLaunchKernelGGL(cs_propagate_ne_lds<unsigned short>, dim3((unsigned)grid), blk, m->lds_bytes, s, tab,
+                         (const unsigned short *)m->d_adj_packed, m->img->n_adj, m->img->packed_obits,
+                         m->img->packed_dmin, in, nodes, out, res, (long long)batch);
+    else
+      hipLaunchKernelGGL(cs_propagate_ne_lds<unsigned int>, dim3((unsigned)grid), blk, m->lds_bytes, s, tab,
+                         (const unsigned int *)m->d_adj_packed, m->img->n_adj, m->img->packed_obits,
+                         m->img->packed_dmin, in, nodes, out, res, (long long)batch);
+    HIP_TRY(hipGetLastError());
+    return CSGPU_OK;
   }
   if (m->has_tree_adj)
     hipLaunchKernelGGL(cs_propagate_events<true>, dim3((unsigned)blocks), dim3(CS_BLOCK), lds, s, tab, in, nodes, out,

@@ -109,7 +109,7 @@ static int32_t emit_tree(tree_ctx *t, int32_t node) {
 
 void cs_dev_image_free(cs_dev_image *g) {
   if (g == NULL) return;
-  free(g->adj_off); free(g->adj); free(g->clause); free(g->tree_off); free(g->tnode); free(g->tkid); free(g->tree_want);
+  free(g->adj_off); free(g->adj); free(g->clause); free(g->tree_off); free(g->tnode); free(g->tkid); free(g->tree_want); free(g->adj_packed);
   free(g);
 }
 
@@ -200,6 +200,29 @@ cs_dev_image *cs_dev_image_build(const cs_model *m, int with_lists, const unsign
     g->adj_off[m->n_vars] = adj.n / 2;
     g->n_adj = adj.n / 2;
     g->adj = adj.v ? adj.v : (int32_t *)calloc(2, sizeof(int32_t));
+    /* packed copy for the LDS-resident kernel: only for pure binary-NE adjacency */
+    if (g->n_tree_clauses == 0 && g->n_adj > 0) {
+      int32_t dmin = g->adj[1], dmax = g->adj[1];
+      for (int32_t i = 0; i < g->n_adj; i++) {
+        if (g->adj[2 * i + 1] < dmin) dmin = g->adj[2 * i + 1];
+        if (g->adj[2 * i + 1] > dmax) dmax = g->adj[2 * i + 1];
+      }
+      int obits = 1, dbits = 1;
+      while ((1 << obits) < m->n_vars) obits++;
+      while (((int64_t)1 << dbits) <= (int64_t)dmax - (int64_t)dmin) dbits++;
+      const int width = obits + dbits <= 16 ? 2 : (obits + dbits <= 32 ? 4 : 0);
+      if (width != 0) {
+        g->packed_width = width;
+        g->packed_obits = obits;
+        g->packed_dmin = dmin;
+        g->adj_packed = malloc((size_t)g->n_adj * (size_t)width);
+        for (int32_t i = 0; i < g->n_adj; i++) {
+          uint32_t e = (uint32_t)g->adj[2 * i] | ((uint32_t)(g->adj[2 * i + 1] - dmin) << obits);
+          if (width == 2) ((uint16_t *)g->adj_packed)[i] = (uint16_t)e;
+          else ((uint32_t *)g->adj_packed)[i] = e;
+        }
+      }
+    }
   } else {
     g->adj = (int32_t *)calloc(2, sizeof(int32_t));
   }

@@ -60,6 +60,10 @@ typedef struct cs_dev_image {
   int32_t *tnode;       /* [4*n_tnodes] */
   int32_t *tkid;        /* [n_tkids] */
   int32_t *tree_want;   /* [2*n_trees] {lo,hi} pushed into each tree root, normally {1,1} */
+  /* packed adjacency of pure binary-NE models for the LDS-resident kernel: entry =
+   * other | (d - packed_dmin) << packed_obits, 2 or 4 bytes wide (0 = not available) */
+  int32_t packed_width, packed_obits, packed_dmin;
+  void *adj_packed;     /* [n_adj] uint16_t or uint32_t */
 } cs_dev_image;
 
 /* with_lists = 0: clause-centric view only (root phase, lists not needed).

@@ -410,6 +410,148 @@ __global__ __launch_bounds__(CS_BLOCK) void cs_propagate_events(cs_tables T, con
   }
 }
 
+/* ---- the hot kernel, LDS-resident variant for pure binary-NE networks ---------------
+ *
+ * Same fixpoint as cs_propagate_events<false>, restructured around what the PMC profile of
+ * that kernel showed (latency-bound on adjacency loads from L2, 1.5x more scalar than vector
+ * instructions):
+ *   - the whole adjacency (packed to 2 or 4 bytes per entry) and adj_off[] are copied into LDS
+ *     once per workgroup; workgroups are persistent (grid = resident workgroups) and up to 16
+ *     waves share one copy, so a clause revision touches LDS only;
+ *   - the changed variable's own interval is read once per list scan into scalars; the scan is
+ *     specialised on it: a VALUE pushes its forbidden value into every neighbour bound
+ *     (propagate_eq_false_lr towards the other side, propagate.c:106-120), an OPEN interval only
+ *     looks for valued neighbours sitting on one of its two bounds.  Each revision therefore
+ *     does one direction, the only one that can fire;
+ *   - revisions are counted per scan (scalar), not per lane.
+ */
+template <typename E>
+__global__ __launch_bounds__(1024) void cs_propagate_ne_lds(cs_tables T, const E *__restrict__ adj_packed, int n_adj,
+                                                            int obits, int dmin,
+                                                            const cs_val *__restrict__ states_in,
+                                                            const cs_node_in *__restrict__ nodes,
+                                                            cs_val *__restrict__ states_out,
+                                                            cs_node_out *__restrict__ results, long long batch) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
+  const int lane = threadIdx.x & (CS_WAVE - 1);
+  const int wave_in_block = threadIdx.x >> 6;
+  const int waves_per_block = blockDim.x >> 6;
+  const int n = T.n_vars, nw = T.n_words;
+  /* LDS: adj_off[n+1] | packed adjacency | one slice per wave (domains + two masks) */
+  int *s_off = (int *)cs_lds;
+  const size_t off_bytes = (((size_t)(n + 1) * sizeof(int)) + 15) & ~(size_t)15;
+  E *s_adj = (E *)(cs_lds + off_bytes);
+  const size_t adj_bytes = (((size_t)n_adj * sizeof(E)) + 15) & ~(size_t)15;
+  const size_t slice = (size_t)n * sizeof(cs_val) + 2 * (size_t)nw * sizeof(unsigned);
+  const size_t slice_al = (slice + 15) & ~(size_t)15;
+  cs_val *dom = (cs_val *)(cs_lds + off_bytes + adj_bytes + wave_in_block * slice_al);
+  unsigned *mask_a = (unsigned *)(dom + n);
+  unsigned *mask_b = mask_a + nw;
+
+  for (int i = threadIdx.x; i <= n; i += blockDim.x) s_off[i] = T.adj_off[i];
+  for (int i = threadIdx.x; i < n_adj; i += blockDim.x) s_adj[i] = adj_packed[i];
+  __syncthreads();
+
+  const unsigned omask = (1u << obits) - 1u;
+  const long long waves_total = (long long)gridDim.x * waves_per_block;
+  for (long long node = (long long)blockIdx.x * waves_per_block + wave_in_block; node < batch; node += waves_total) {
+    const cs_node_in nin = nodes[node];
+    const cs_val *src = states_in + (size_t)nin.parent * n;
+    for (int v = lane; v < n; v += CS_WAVE) dom[v] = src[v];
+    for (int w = lane; w < nw; w += CS_WAVE) { mask_a[w] = 0u; mask_b[w] = 0u; }
+    cs_wave_sync();
+    if (nin.var >= 0) {
+      if (lane == 0) {
+        dom[nin.var] = cs_interval(nin.lo, nin.hi);
+        mask_a[nin.var >> 5] = 1u << (nin.var & 31);
+      }
+    } else {
+      for (int w = lane; w < nw; w += CS_WAVE) {
+        int rem = n - w * 32;
+        mask_a[w] = rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u);
+      }
+    }
+    cs_wave_sync();
+
+    cs_ctx cx;
+    cx.dom = dom;
+    cx.mark_is_flag = 0;
+    cx.fail = 0;
+    cx.props = 0;
+    cx.revisions = 0;
+    unsigned *cur = mask_a, *nxt = mask_b;
+    int rounds = 0, failed = 0, revisions = 0;
+    for (;;) {
+      cx.mark = nxt;
+      int any = 0;
+      for (int w = 0; w < nw && !failed; w++) {
+        unsigned bits = __builtin_amdgcn_readfirstlane(cur[w]);
+        any |= bits != 0u;
+        while (bits != 0u) {
+          const int u = w * 32 + __builtin_ctz(bits);
+          bits &= bits - 1u;
+          const cs_val du = dom[u];
+          const int ulo = __builtin_amdgcn_readfirstlane(du.lo), uhi = __builtin_amdgcn_readfirstlane(du.hi);
+          if (ulo > uhi) { failed = 1; break; } /* bounds crossed by racing updates */
+          const int beg = __builtin_amdgcn_readfirstlane(s_off[u]), end = __builtin_amdgcn_readfirstlane(s_off[u + 1]);
+          revisions += end - beg;
+          if (ulo == uhi) {
+            /* u is a value: every neighbour must avoid ulo - d */
+            for (int i = beg + lane; i < end; i += CS_WAVE) {
+              const unsigned e = s_adj[i];
+              const int wv = (int)(e & omask);
+              const int f = ulo - ((int)(e >> obits) + dmin);
+              const cs_val dw = dom[wv];
+              if (dw.lo == f) cx.raise_lo(wv, f + 1);
+              else if (dw.hi == f) cx.lower_hi(wv, f - 1);
+            }
+          } else {
+            /* u is open: only a valued neighbour sitting on one of u's bounds can shave it */
+            for (int i = beg + lane; i < end; i += CS_WAVE) {
+              const unsigned e = s_adj[i];
+              const cs_val dw = dom[e & omask];
+              if (dw.lo == dw.hi) {
+                const int f = dw.lo + (int)(e >> obits) + dmin;
+                if (f == ulo) cx.raise_lo(u, f + 1);
+                else if (f == uhi) cx.lower_hi(u, f - 1);
+              }
+            }
+          }
+          if (__any(cx.fail)) { failed = 1; break; }
+        }
+      }
+      if (failed || !any) break;
+      rounds++;
+      cs_wave_sync();
+      for (int w = lane; w < nw; w += CS_WAVE) cur[w] = 0u;
+      cs_wave_sync();
+      unsigned *t = cur; cur = nxt; nxt = t;
+    }
+    cs_wave_sync();
+
+    int props = cx.props;
+    for (int off = 32; off > 0; off >>= 1) props += __shfl_xor(props, off);
+    int open_vars = 0;
+    if (!failed) {
+      cs_val *dst = states_out + (size_t)node * n;
+      for (int v = lane; v < n; v += CS_WAVE) {
+        const cs_val d = dom[v];
+        dst[v] = d;
+        open_vars += __popcll(__ballot(d.lo != d.hi));
+      }
+    }
+    if (lane == 0) {
+      cs_node_out r;
+      r.status = failed ? -1 : open_vars;
+      r.props = props;
+      r.revisions = revisions;
+      r.rounds = rounds;
+      results[node] = r;
+    }
+    cs_wave_sync();
+  }
+}
+
 /* ---- full sweeps (root phase): one workgroup per instance ------------------------ */
 
 __global__ __launch_bounds__(CS_BLOCK) void cs_propagate_sweeps(cs_tables T, const cs_val *__restrict__ states_in,

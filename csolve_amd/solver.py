@@ -122,6 +122,14 @@ class Model:
         self.finalized = True
         return self
 
+    def set_kernel(self, which: int):
+        """0 automatic, 1 general kernel, 2 LDS-resident kernel (pure binary-NE models that fit)"""
+        check(load_library().csgpu_model_set_kernel(self._h, which))
+        return self
+
+    def kernel(self) -> int:
+        return check(load_library().csgpu_model_get_kernel(self._h))
+
     def root_state(self, device="cuda") -> torch.Tensor:
         """[1, n_vars, 2] int32 tensor of the root domains."""
         return torch.from_numpy(self.domains()).to(device).unsqueeze(0).contiguous()

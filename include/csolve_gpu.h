@@ -111,6 +111,14 @@ int csgpu_model_build_tables(csgpu_model *m);
  * CSGPU_E_UNBOUNDED if a variable still has an infinite bound. */
 int csgpu_model_finalize(csgpu_model *m);
 
+/* Kernel selection for the batched fixpoint: 0 = automatic (default), 1 = the general kernel
+ * (adjacency read through L2; handles tree clauses), 2 = the LDS-resident kernel (pure binary-NE
+ * models whose packed adjacency fits in LDS; CSGPU_E_LIMIT if the model does not qualify).
+ * Both compute the same results; tests run every parity case through each of them. */
+int csgpu_model_set_kernel(csgpu_model *m, int which);
+/* which kernel csgpu_propagate_batch will launch: 1 or 2 (see above) */
+int csgpu_model_get_kernel(const csgpu_model *m);
+
 /* ---- batched propagation (the hot path) ----
  * d_states_in : device, [*][n_vars] csgpu_val   parent states
  * d_nodes     : device, [batch] csgpu_node      (parent = row of d_states_in)

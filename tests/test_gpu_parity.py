@@ -18,6 +18,11 @@ WALKS_WITH_MODEL = sorted(os.path.basename(p)[:-8] for p in glob.glob(golden("wa
                           if os.path.exists(golden("models", os.path.basename(p)[:-8] + ".model")))
 
 
+def _kernels(model):
+    """every kernel that can run this model: 1 = general, 2 = LDS-resident (when it qualifies)"""
+    return [1, 2] if model.kernel() == 2 else [1]
+
+
 def _gpu_walk(model, walk):
     before = torch.from_numpy(walk["before"]).cuda().contiguous()
     B = before.shape[0]
@@ -35,13 +40,17 @@ def test_reference_walks_on_reference_model(name):
     from oracle.cs_oracle import read_walk
     walk = read_walk(golden("walks", name + ".walk.gz"))
     model = Model.from_dump(golden("models", name + ".model")).finalize()
-    out, res = _gpu_walk(model, walk)
-    fail_ref = walk["status"] < 0
-    assert ((res[:, 0] < 0) == fail_ref).all()
-    ok = ~fail_ref
-    assert (out[ok] == walk["after"][ok]).all()
     if name in NE_ONLY:
-        assert (res[ok, 1] == walk["status"][ok]).all()
+        assert model.kernel() == 2, "pure != networks of this size must take the LDS-resident kernel"
+    for k in _kernels(model):
+        model.set_kernel(k)
+        out, res = _gpu_walk(model, walk)
+        fail_ref = walk["status"] < 0
+        assert ((res[:, 0] < 0) == fail_ref).all()
+        ok = ~fail_ref
+        assert (out[ok] == walk["after"][ok]).all()
+        if name in NE_ONLY:
+            assert (res[ok, 1] == walk["status"][ok]).all()
 
 
 @pytest.mark.parametrize("name", sorted(os.path.basename(p)[:-8] for p in glob.glob(golden("walks", "*.walk.gz"))))
@@ -53,11 +62,13 @@ def test_reference_walks_through_own_front_end(name):
     walk = read_walk(golden("walks", name + ".walk.gz"))
     model = solve_root(open(golden("problems", name + ".txt")).read())
     assert model.n_vars == walk["n_vars"]
-    out, res = _gpu_walk(model, walk)
-    fail_ref = walk["status"] < 0
-    assert ((res[:, 0] < 0) == fail_ref).all()
-    ok = ~fail_ref
-    assert (out[ok] == walk["after"][ok]).all()
+    for k in _kernels(model):
+        model.set_kernel(k)
+        out, res = _gpu_walk(model, walk)
+        fail_ref = walk["status"] < 0
+        assert ((res[:, 0] < 0) == fail_ref).all()
+        ok = ~fail_ref
+        assert (out[ok] == walk["after"][ok]).all()
 
 
 @pytest.mark.parametrize("name", ["queens8", "queens64", "ref_sudoku", "ref_schedule", "ref_wcet", "schedule6_s1"])
@@ -102,8 +113,10 @@ def _random_nodes(rng, states, count):
     return nodes
 
 
-@pytest.mark.parametrize("kind,size", [("queens", 64), ("queens", 128), ("sudoku", 5), ("schedule", 16)])
-def test_batch_vs_oracle_and_properties(kind, size):
+@pytest.mark.parametrize("kind,size,kernel", [("queens", 64, 1), ("queens", 64, 2), ("queens", 128, 1),
+                                              ("queens", 128, 2), ("sudoku", 5, 1), ("sudoku", 5, 2),
+                                              ("schedule", 16, 1)])
+def test_batch_vs_oracle_and_properties(kind, size, kernel):
     """Seeded multi-level batches at the BASELINE sizes: a sample is checked against the oracle
     bit for bit; the whole batch is checked through properties -- the output is contained in the
     input, is a fixpoint (re-propagating it with every variable marked changed narrows nothing),
@@ -114,6 +127,8 @@ def test_batch_vs_oracle_and_properties(kind, size):
     text = {"queens": lambda: problems.queens(size), "sudoku": lambda: problems.sudoku(size, 0.4, 1),
             "schedule": lambda: problems.schedule(size, 1)}[kind]()
     model = solve_root(text)
+    model.set_kernel(kernel)
+    assert model.kernel() == kernel
     n = model.n_vars
     omodel = OModel.parse(text)
     omodel.set_domains(model.domains())

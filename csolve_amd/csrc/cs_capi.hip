@@ -317,6 +317,35 @@ extern "C" int csgpu_model_eval_clauses_host(csgpu_model *m, csgpu_val *vals) {
   return rc;
 }
 
+/* instantiation of the LDS-resident kernel for an entry width and a prefetch depth
+ * R = ceil(n_vars / 64) rounded up to a power of two (at most 16: larger states load their tail in place) */
+static const void *ne_lds_kernel(int width, int n_vars) {
+  int r = 1;
+  while (r < 16 && r * CS_WAVE < n_vars) r <<= 1;
+  /* list strides fetched together; experiment knob, default 1 */
+  static int unroll = -1;
+  if (unroll < 0) {
+    const char *e = getenv("CSGPU_NE_UNROLL");
+    unroll = e != NULL && atoi(e) == 4 ? 4 : (e != NULL && atoi(e) == 2 ? 2 : 1);
+  }
+#define CS_PICK_U(E, RR)                                                                           \
+  return unroll == 4 ? (const void *)cs_propagate_ne_lds<E, RR, 4>                                  \
+                     : (unroll == 2 ? (const void *)cs_propagate_ne_lds<E, RR, 2>                    \
+                                    : (const void *)cs_propagate_ne_lds<E, RR, 1>);
+#define CS_PICK(E)                                                                                 \
+  switch (r) {                                                                                     \
+  case 1: CS_PICK_U(E, 1)                                                                          \
+  case 2: CS_PICK_U(E, 2)                                                                          \
+  case 4: CS_PICK_U(E, 4)                                                                          \
+  case 8: CS_PICK_U(E, 8)                                                                          \
+  default: CS_PICK_U(E, 16)                                                                        \
+  }
+  if (width == 2) { CS_PICK(unsigned short) }
+  CS_PICK(unsigned int)
+#undef CS_PICK
+#undef CS_PICK_U
+}
+
 /* ---- finalize ---------------------------------------------------------------------- */
 
 extern "C" int csgpu_model_build_tables(csgpu_model *m) {
@@ -402,10 +431,11 @@ extern "C" int csgpu_model_finalize(csgpu_model *m) {
   /* LDS-resident kernel: adj_off + packed adjacency + one slice per wave must fit in a CU's LDS */
   m->lds_waves = 0;
   if (m->img->packed_width != 0) {
-    const size_t off_bytes = (((size_t)(h->n_vars + 1) * sizeof(int)) + 15) & ~(size_t)15;
+    const size_t off_bytes = (((size_t)h->n_vars * 2 * sizeof(int)) + 15) & ~(size_t)15;
     const size_t adj_bytes = (((size_t)m->img->n_adj * (size_t)m->img->packed_width) + 15) & ~(size_t)15;
+    const size_t lds_slice = ((size_t)h->n_vars * sizeof(cs_val) + (2 * (size_t)m->tab.n_words + 1) * sizeof(unsigned) + 15) & ~(size_t)15;
     for (int waves = 16; waves >= 4; waves >>= 1) {
-      const size_t need = off_bytes + adj_bytes + (size_t)waves * m->slice;
+      const size_t need = off_bytes + adj_bytes + (size_t)waves * lds_slice;
       if (need <= 160u * 1024u) {
         m->lds_waves = waves;
         m->lds_bytes = need;
@@ -416,9 +446,7 @@ extern "C" int csgpu_model_finalize(csgpu_model *m) {
       if ((rc = upload(m->img->adj_packed, (size_t)m->img->n_adj * (size_t)m->img->packed_width,
                        (int **)&m->d_adj_packed)))
         return rc;
-      const void *fn = m->img->packed_width == 2 ? (const void *)cs_propagate_ne_lds<unsigned short>
-                                                 : (const void *)cs_propagate_ne_lds<unsigned int>;
-      if ((rc = lds_limit(m->lds_bytes, fn))) return rc;
+      if ((rc = lds_limit(m->lds_bytes, ne_lds_kernel(m->img->packed_width, h->n_vars)))) return rc;
     }
   }
 
@@ -497,15 +525,12 @@ extern "C" int csgpu_propagate_batch_obj(const csgpu_model *m, const csgpu_val *
     const int64_t need = (batch + m->lds_waves - 1) / m->lds_waves;
     if (grid > need) grid = need;
     const dim3 blk((unsigned)(m->lds_waves * CS_WAVE));
-    if (m->img->packed_width == 2)
-      hipLaunchKernelGGL(cs_propagate_ne_lds<unsigned short>, dim3((unsigned)grid), blk, m->lds_bytes, s, tab,
-                         (const unsigned short *)m->d_adj_packed, m->img->n_adj, m->img->packed_obits,
-                         m->img->packed_dmin, in, nodes, out, res, (long long)batch);
-    else
-      hipLaunchKernelGGL(cs_propagate_ne_lds<unsigned int>, dim3((unsigned)grid), blk, m->lds_bytes, s, tab,
-                         (const unsigned int *)m->d_adj_packed, m->img->n_adj, m->img->packed_obits,
-                         m->img->packed_dmin, in, nodes, out, res, (long long)batch);
-    HIP_TRY(hipGetLastError());
+    int n_adj = m->img->n_adj, obits = m->img->packed_obits, dmin = m->img->packed_dmin;
+    long long nb = (long long)batch;
+    const void *packed = m->d_adj_packed;
+    void *args[] = { &tab, &packed, &n_adj, &obits, &dmin, &in, &nodes, &out, &res, &nb };
+    HIP_TRY(hipLaunchKernel(ne_lds_kernel(m->img->packed_width, m->host->n_vars), dim3((unsigned)grid), blk, args,
+                            m->lds_bytes, s));
     return CSGPU_OK;
   }
   if (m->has_tree_adj)

@@ -425,8 +425,10 @@ __global__ __launch_bounds__(CS_BLOCK) void cs_propagate_events(cs_tables T, con
  *     does one direction, the only one that can fire;
  *   - revisions are counted per scan (scalar), not per lane.
  */
-template <typename E>
-__global__ __launch_bounds__(1024) void cs_propagate_ne_lds(cs_tables T, const E *__restrict__ adj_packed, int n_adj,
+#define CS_CHUNK 16 /* nodes a wave takes at a time: their records sit in lanes 0..15 */
+
+template <typename E, int R, int U>
+__global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_lds(cs_tables T, const E *__restrict__ adj_packed, int n_adj,
                                                             int obits, int dmin,
                                                             const cs_val *__restrict__ states_in,
                                                             const cs_node_in *__restrict__ nodes,
@@ -437,118 +439,177 @@ __global__ __launch_bounds__(1024) void cs_propagate_ne_lds(cs_tables T, const E
   const int wave_in_block = threadIdx.x >> 6;
   const int waves_per_block = blockDim.x >> 6;
   const int n = T.n_vars, nw = T.n_words;
-  /* LDS: adj_off[n+1] | packed adjacency | one slice per wave (domains + two masks) */
-  int *s_off = (int *)cs_lds;
-  const size_t off_bytes = (((size_t)(n + 1) * sizeof(int)) + 15) & ~(size_t)15;
+  /* LDS: {begin,end} of every list [n] | packed adjacency | one slice per wave
+   * (domains, two masks, the propagation counter) */
+  int2 *s_off2 = (int2 *)cs_lds;
+  const size_t off_bytes = (((size_t)n * sizeof(int2)) + 15) & ~(size_t)15;
   E *s_adj = (E *)(cs_lds + off_bytes);
   const size_t adj_bytes = (((size_t)n_adj * sizeof(E)) + 15) & ~(size_t)15;
-  const size_t slice = (size_t)n * sizeof(cs_val) + 2 * (size_t)nw * sizeof(unsigned);
+  const size_t slice = (size_t)n * sizeof(cs_val) + (2 * (size_t)nw + 1) * sizeof(unsigned);
   const size_t slice_al = (slice + 15) & ~(size_t)15;
   cs_val *dom = (cs_val *)(cs_lds + off_bytes + adj_bytes + wave_in_block * slice_al);
   unsigned *mask_a = (unsigned *)(dom + n);
   unsigned *mask_b = mask_a + nw;
+  unsigned *pcount = mask_b + nw;
 
-  for (int i = threadIdx.x; i <= n; i += blockDim.x) s_off[i] = T.adj_off[i];
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s_off2[i] = make_int2(T.adj_off[i], T.adj_off[i + 1]);
   for (int i = threadIdx.x; i < n_adj; i += blockDim.x) s_adj[i] = adj_packed[i];
   __syncthreads();
 
   const unsigned omask = (1u << obits) - 1u;
+  const long long chunks = (batch + CS_CHUNK - 1) / CS_CHUNK;
   const long long waves_total = (long long)gridDim.x * waves_per_block;
-  for (long long node = (long long)blockIdx.x * waves_per_block + wave_in_block; node < batch; node += waves_total) {
-    const cs_node_in nin = nodes[node];
-    const cs_val *src = states_in + (size_t)nin.parent * n;
-    for (int v = lane; v < n; v += CS_WAVE) dom[v] = src[v];
-    for (int w = lane; w < nw; w += CS_WAVE) { mask_a[w] = 0u; mask_b[w] = 0u; }
-    cs_wave_sync();
-    if (nin.var >= 0) {
-      if (lane == 0) {
-        dom[nin.var] = cs_interval(nin.lo, nin.hi);
-        mask_a[nin.var >> 5] = 1u << (nin.var & 31);
-      }
-    } else {
-      for (int w = lane; w < nw; w += CS_WAVE) {
-        int rem = n - w * 32;
-        mask_a[w] = rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u);
+  for (long long chunk = (long long)blockIdx.x * waves_per_block + wave_in_block; chunk < chunks; chunk += waves_total) {
+    const long long base = chunk * CS_CHUNK;
+    const int cnt = (int)(batch - base < CS_CHUNK ? batch - base : CS_CHUNK);
+    /* the chunk's node records: one coalesced 16-byte load per lane, then register reads only */
+    cs_node_in rec;
+    rec.var = -1; rec.lo = 0; rec.hi = 0; rec.parent = 0;
+    if (lane < cnt) rec = nodes[base + lane];
+    cs_node_out my_result;
+    my_result.status = 0; my_result.props = 0; my_result.revisions = 0; my_result.rounds = 0;
+
+    /* software pipeline: the state of node j+1 is in flight while node j is propagated */
+    cs_val pre[R];
+    {
+      const cs_val *src = states_in + (size_t)__builtin_amdgcn_readlane(rec.parent, 0) * n;
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        const int v = lane + r * CS_WAVE;
+        pre[r] = v < n ? src[v] : cs_value(0);
       }
     }
-    cs_wave_sync();
-
-    cs_ctx cx;
-    cx.dom = dom;
-    cx.mark_is_flag = 0;
-    cx.fail = 0;
-    cx.props = 0;
-    cx.revisions = 0;
-    unsigned *cur = mask_a, *nxt = mask_b;
-    int rounds = 0, failed = 0, revisions = 0;
-    for (;;) {
-      cx.mark = nxt;
-      int any = 0;
-      for (int w = 0; w < nw && !failed; w++) {
-        unsigned bits = __builtin_amdgcn_readfirstlane(cur[w]);
-        any |= bits != 0u;
-        while (bits != 0u) {
-          const int u = w * 32 + __builtin_ctz(bits);
-          bits &= bits - 1u;
-          const cs_val du = dom[u];
-          const int ulo = __builtin_amdgcn_readfirstlane(du.lo), uhi = __builtin_amdgcn_readfirstlane(du.hi);
-          if (ulo > uhi) { failed = 1; break; } /* bounds crossed by racing updates */
-          const int beg = __builtin_amdgcn_readfirstlane(s_off[u]), end = __builtin_amdgcn_readfirstlane(s_off[u + 1]);
-          revisions += end - beg;
-          if (ulo == uhi) {
-            /* u is a value: every neighbour must avoid ulo - d */
-            for (int i = beg + lane; i < end; i += CS_WAVE) {
-              const unsigned e = s_adj[i];
-              const int wv = (int)(e & omask);
-              const int f = ulo - ((int)(e >> obits) + dmin);
-              const cs_val dw = dom[wv];
-              if (dw.lo == f) cx.raise_lo(wv, f + 1);
-              else if (dw.hi == f) cx.lower_hi(wv, f - 1);
-            }
-          } else {
-            /* u is open: only a valued neighbour sitting on one of u's bounds can shave it */
-            for (int i = beg + lane; i < end; i += CS_WAVE) {
-              const unsigned e = s_adj[i];
-              const cs_val dw = dom[e & omask];
-              if (dw.lo == dw.hi) {
-                const int f = dw.lo + (int)(e >> obits) + dmin;
-                if (f == ulo) cx.raise_lo(u, f + 1);
-                else if (f == uhi) cx.lower_hi(u, f - 1);
-              }
-            }
-          }
-          if (__any(cx.fail)) { failed = 1; break; }
+    for (int j = 0; j < cnt; j++) {
+      const int nvar = __builtin_amdgcn_readlane(rec.var, j);
+      const int nlo = __builtin_amdgcn_readlane(rec.lo, j), nhi = __builtin_amdgcn_readlane(rec.hi, j);
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        const int v = lane + r * CS_WAVE;
+        if (v < n) dom[v] = pre[r];
+      }
+      for (int v = lane + R * CS_WAVE; v < n; v += CS_WAVE) /* n > 64*R: the tail is loaded in place */
+        dom[v] = states_in[(size_t)__builtin_amdgcn_readlane(rec.parent, j) * n + v];
+      if (j + 1 < cnt) {
+        const cs_val *src = states_in + (size_t)__builtin_amdgcn_readlane(rec.parent, j + 1) * n;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          const int v = lane + r * CS_WAVE;
+          pre[r] = v < n ? src[v] : cs_value(0);
         }
       }
-      if (failed || !any) break;
-      rounds++;
+      for (int w = lane; w < nw; w += CS_WAVE) { mask_a[w] = 0u; mask_b[w] = 0u; }
+      if (lane == 0) *pcount = 0u;
       cs_wave_sync();
-      for (int w = lane; w < nw; w += CS_WAVE) cur[w] = 0u;
-      cs_wave_sync();
-      unsigned *t = cur; cur = nxt; nxt = t;
-    }
-    cs_wave_sync();
-
-    int props = cx.props;
-    for (int off = 32; off > 0; off >>= 1) props += __shfl_xor(props, off);
-    int open_vars = 0;
-    if (!failed) {
-      cs_val *dst = states_out + (size_t)node * n;
-      for (int v = lane; v < n; v += CS_WAVE) {
-        const cs_val d = dom[v];
-        dst[v] = d;
-        open_vars += __popcll(__ballot(d.lo != d.hi));
+      if (nvar >= 0) {
+        if (lane == 0) {
+          dom[nvar] = cs_interval(nlo, nhi);
+          mask_a[nvar >> 5] = 1u << (nvar & 31);
+        }
+      } else {
+        for (int w = lane; w < nw; w += CS_WAVE) {
+          int rem = n - w * 32;
+          mask_a[w] = rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u);
+        }
       }
+      cs_wave_sync();
+
+      unsigned *cur = mask_a, *nxt = mask_b;
+      int rounds = 0, failed = 0, revisions = 0, fail = 0;
+      /* narrowing: LDS atomic on the bound; the lane whose atomic moved it books the propagation
+       * in the node's LDS counter and marks the variable for the next round */
+#define CS_RAISE(V, LO)                                                        \
+  do {                                                                         \
+    const int v_ = (V), lo_ = (LO);                                            \
+    if (atomicMax(&dom[v_].lo, lo_) < lo_) {                                   \
+      atomicAdd(pcount, 1u);                                                   \
+      atomicOr(&nxt[v_ >> 5], 1u << (v_ & 31));                                \
+      if (lo_ > dom[v_].hi) fail = 1;                                          \
+    }                                                                          \
+  } while (0)
+#define CS_LOWER(V, HI)                                                        \
+  do {                                                                         \
+    const int v_ = (V), hi_ = (HI);                                            \
+    if (atomicMin(&dom[v_].hi, hi_) > hi_) {                                   \
+      atomicAdd(pcount, 1u);                                                   \
+      atomicOr(&nxt[v_ >> 5], 1u << (v_ & 31));                                \
+      if (hi_ < dom[v_].lo) fail = 1;                                          \
+    }                                                                          \
+  } while (0)
+      for (;;) {
+        int any = 0;
+        for (int w = 0; w < nw && !failed; w++) {
+          unsigned bits = __builtin_amdgcn_readfirstlane(cur[w]);
+          any |= bits != 0u;
+          while (bits != 0u) {
+            const int u = w * 32 + __builtin_ctz(bits);
+            bits &= bits - 1u;
+            const cs_val du = dom[u];
+            const int2 range = s_off2[u]; /* {begin, end} in one LDS read */
+            const int ulo = __builtin_amdgcn_readfirstlane(du.lo), uhi = __builtin_amdgcn_readfirstlane(du.hi);
+            if (ulo > uhi) { failed = 1; break; } /* bounds crossed by racing updates */
+            const int beg = __builtin_amdgcn_readfirstlane(range.x), end = __builtin_amdgcn_readfirstlane(range.y);
+            revisions += end - beg;
+            const int is_value = ulo == uhi;
+            /* U strides at a time: all entry reads, then all domain reads, then the compares */
+            for (int i0 = beg + lane; i0 < end; i0 += U * CS_WAVE) {
+              unsigned e[U];
+              cs_val dw[U];
+#pragma unroll
+              for (int k = 0; k < U; k++) {
+                const int i = i0 + k * CS_WAVE;
+                e[k] = i < end ? (unsigned)s_adj[i] : 0xffffffffu;
+              }
+#pragma unroll
+              for (int k = 0; k < U; k++) dw[k] = e[k] != 0xffffffffu ? dom[e[k] & omask] : cs_interval(1, 0);
+#pragma unroll
+              for (int k = 0; k < U; k++) {
+                if (e[k] == 0xffffffffu) continue;
+                const int wv = (int)(e[k] & omask);
+                const int d = (int)(e[k] >> obits) + dmin;
+                if (is_value) { /* u is a value: the neighbour must avoid ulo - d */
+                  const int f = ulo - d;
+                  if (dw[k].lo == f) CS_RAISE(wv, f + 1);
+                  else if (dw[k].hi == f) CS_LOWER(wv, f - 1);
+                } else if (dw[k].lo == dw[k].hi) { /* u is open: a valued neighbour on one of its bounds */
+                  const int f = dw[k].lo + d;
+                  if (f == ulo) CS_RAISE(u, f + 1);
+                  else if (f == uhi) CS_LOWER(u, f - 1);
+                }
+              }
+            }
+            if (__any(fail)) { failed = 1; break; }
+          }
+        }
+        if (failed || !any) break;
+        rounds++;
+        cs_wave_sync();
+        for (int w = lane; w < nw; w += CS_WAVE) cur[w] = 0u;
+        cs_wave_sync();
+        unsigned *t = cur; cur = nxt; nxt = t;
+      }
+#undef CS_RAISE
+#undef CS_LOWER
+      cs_wave_sync();
+
+      const int props = (int)*pcount;
+      int open_vars = 0;
+      if (!failed) {
+        cs_val *dst = states_out + (size_t)(base + j) * n;
+        for (int v = lane; v < n; v += CS_WAVE) {
+          const cs_val d = dom[v];
+          dst[v] = d;
+          open_vars += __popcll(__ballot(d.lo != d.hi));
+        }
+      }
+      if (lane == j) { /* lane j keeps node j's result; one coalesced store per chunk */
+        my_result.status = failed ? -1 : open_vars;
+        my_result.props = props;
+        my_result.revisions = revisions;
+        my_result.rounds = rounds;
+      }
+      cs_wave_sync();
     }
-    if (lane == 0) {
-      cs_node_out r;
-      r.status = failed ? -1 : open_vars;
-      r.props = props;
-      r.revisions = revisions;
-      r.rounds = rounds;
-      results[node] = r;
-    }
-    cs_wave_sync();
+    if (lane < cnt) results[base + lane] = my_result;
   }
 }
 

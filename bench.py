@@ -39,19 +39,27 @@ from csolve_amd.solver import solve_root  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def make_instances(model, count, seed, walks=8192):
-    """Seeded random walks on the device path.  -> states_in [count,n,2] (cuda), nodes [count,4] (cuda)"""
+def make_instances(model, count, seed, walks=8192, with_sets=False):
+    """Seeded random walks on the device path.
+    -> states_in [count,n,2], nodes [count,4], forb_in [count,n,FW] or None   (all on the device)"""
     n = model.n_vars
     root = model.domains()
     rng = np.random.default_rng(seed)
     walks = min(walks, count)
     cur = np.repeat(root[None], walks, 0)
-    states, nodes = [], []
+    root_forb = cur_forb = None
+    if with_sets:
+        full = torch.tensor([[-1, 0, 0, 0]], dtype=torch.int32, device="cuda")
+        _, root_forb, _ = model.propagate_fb(model.root_state(), full)
+        cur_forb = root_forb.repeat(walks, 1, 1).contiguous()
+    states, nodes, forbs = [], [], []
     have = 0
     while have < count:
         open_mask = cur[:, :, 0] < cur[:, :, 1]
         done = ~open_mask.any(1)
         cur[done] = root
+        if with_sets and done.any():
+            cur_forb[torch.from_numpy(done).cuda()] = root_forb[0]
         open_mask[done] = root[:, 0] < root[:, 1]
         # random open variable per walk, random value of its interval
         keys = rng.random(open_mask.shape)
@@ -62,19 +70,28 @@ def make_instances(model, count, seed, walks=8192):
         val = lo + (rng.random(walks) * (hi - lo + 1)).astype(np.int64).clip(0, hi - lo)
         nd = np.stack([var, val, val, np.arange(walks)], 1).astype(np.int32)
         d_cur = torch.from_numpy(cur).cuda()
-        out, res = model.propagate(d_cur, torch.from_numpy(nd).cuda())
+        if with_sets:
+            out, fout, res = model.propagate_fb(d_cur, torch.from_numpy(nd).cuda(), forb_in=cur_forb)
+        else:
+            out, res = model.propagate(d_cur, torch.from_numpy(nd).cuda())
         torch.cuda.synchronize()
         take = min(walks, count - have)
         states.append(d_cur[:take].clone())
+        if with_sets:
+            forbs.append(cur_forb[:take].clone())
         nd_take = nd[:take].copy()
         nd_take[:, 3] = np.arange(have, have + take)
         nodes.append(torch.from_numpy(nd_take).cuda())
         have += take
-        ok = (res[:, 0] >= 0).cpu().numpy()
+        okt = res[:, 0] >= 0
+        ok = okt.cpu().numpy()
         nxt = out.cpu().numpy()
         nxt[~ok] = root
         cur = nxt
-    return torch.cat(states).contiguous(), torch.cat(nodes).contiguous()
+        if with_sets:
+            cur_forb = torch.where(okt[:, None, None], fout, root_forb.expand_as(fout)).contiguous()
+    return (torch.cat(states).contiguous(), torch.cat(nodes).contiguous(),
+            torch.cat(forbs).contiguous() if with_sets else None)
 
 
 REF_BIN = os.path.join(ROOT, "oracle", "_ref", "csolve_ref")
@@ -218,7 +235,8 @@ def main():
     ap.add_argument("--instances", type=int, default=1 << 18, help="node instances per GPU")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 general, 2 LDS-resident")
+    ap.add_argument("--kernel", type=int, default=0, help="0 best, 1 general, 2 LDS-resident, 3 forbidden-set")
+    ap.add_argument("--rebuild-sets", action="store_true", help="forbidden-set kernel without resident sets")
     ap.add_argument("--workload", choices=["propagate", "search"], default="propagate")
     ap.add_argument("--search-queens", type=int, default=13)
     ap.add_argument("--pool", type=int, default=1 << 21)
@@ -252,15 +270,29 @@ def main():
     n_q = args.queens
     text = problems.queens(n_q)
     model = solve_root(text)
-    model.set_kernel(args.kernel)
-    kernel_name = {1: "cs_propagate_events", 2: "cs_propagate_ne_lds"}[model.kernel()]
+    # kernel: 0 = best available (forbidden-set kernel with the sets resident next to the states),
+    # 1 general, 2 LDS-resident unit shaving, 3 forbidden-set kernel
+    fw = model.forbidden_words()
+    use_sets = fw > 0 and args.kernel in (0, 3) and not args.rebuild_sets
+    if args.kernel in (1, 2) or (args.kernel == 3 and not use_sets):
+        model.set_kernel(args.kernel)
+    kernel_name = "cs_propagate_ne_bitset" if (use_sets or args.kernel == 3) else \
+        {1: "cs_propagate_events", 2: "cs_propagate_ne_lds", 3: "cs_propagate_ne_bitset"}[model.kernel()]
     n = model.n_vars
     info = model.device_info()
 
-    states_in, nodes = make_instances(model, args.instances, seed=12345 + rank)
+    states_in, nodes, forb_in = make_instances(model, args.instances, seed=12345 + rank, with_sets=use_sets)
     B = nodes.shape[0]
     states_out = torch.empty((B, n, 2), dtype=torch.int32, device="cuda")
     results = torch.empty((B, 4), dtype=torch.int32, device="cuda")
+    forb_out = torch.empty((B, n, fw), dtype=torch.int64, device="cuda") if use_sets else None
+
+    def step():
+        if use_sets:
+            model.propagate_fb(states_in, nodes, forb_in=forb_in, states_out=states_out, forb_out=forb_out,
+                               results=results)
+        else:
+            model.propagate(states_in, nodes, states_out, results)
 
     def barrier():
         if dist is not None:
@@ -268,13 +300,13 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        model.propagate(states_in, nodes, states_out, results)
+        step()
     barrier()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for k in range(args.steps):
         ev[k][0].record()
-        model.propagate(states_in, nodes, states_out, results)
+        step()
         ev[k][1].record()
     barrier()
     t1 = time.perf_counter()
@@ -295,7 +327,8 @@ def main():
     # 32 B per clause revision + 8 B per narrowing + 16 B * n per node instance
     alg_bytes = 32 * revs_r + 8 * props_r + 16 * n * B
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-    stream_bytes = (16 * n + 16 + 16) * B  # what must cross HBM: state in + out, node record, result
+    # what must cross HBM per node: state in + out (+ forbidden sets in + out), node record, result
+    stream_bytes = (16 * n + (16 * n * fw if use_sets else 0) + 16 + 16) * B
     out = {
         "metric": "constraint propagations/sec + nodes/sec, queens-N, 1/2/4/8 MI355X",
         "value": props_all * args.steps / elapsed,
@@ -313,7 +346,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"queens-{n_q} propagation-only fixpoint (BASELINE configs[1]), seeded random-walk "
                                f"node instances resident in HBM",
-                   "instances_per_gpu": B, "variables": n, "clauses": info["ne_clauses"] + info["tree_clauses"],
+                   "instances_per_gpu": B, "variables": n, "forbidden_sets_resident": bool(use_sets), "clauses": info["ne_clauses"] + info["tree_clauses"],
                    "inconsistent_fraction": fails_all / nodes_all,
                    "props_per_node": props_all / nodes_all, "revisions_per_node": revs_all / nodes_all},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

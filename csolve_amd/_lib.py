@@ -84,6 +84,8 @@ def load_library():
     L.csgpu_model_get_kernel.argtypes = [vp]
     L.csgpu_propagate_batch.argtypes = [vp, vp, vp, vp, vp, i64, vp]
     L.csgpu_propagate_batch_obj.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, vp]
+    L.csgpu_model_forbidden_words.argtypes = [vp]
+    L.csgpu_propagate_batch_fb.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, vp]
     L.csgpu_eval_batch.argtypes = [vp, vp, vp, i64, vp]
     L.csgpu_eval_clauses.argtypes = [vp, vp, vp, vp]
     L.csgpu_search_create.argtypes = [vp, i64, i64, C.POINTER(vp)]

@@ -47,6 +47,12 @@ struct csgpu_model {
   void *d_adj_packed;
   int lds_waves;     /* waves per workgroup of the LDS-resident kernel, 0 = not eligible */
   size_t lds_bytes;  /* its dynamic LDS size */
+  int fb_words;      /* forbidden-set words per variable (0 = not eligible) */
+  int fb_waves;
+  size_t fb_bytes;
+  int *d_root_lo;
+  int *d_sym_off;
+  void *d_sym_packed;
   int n_cus;
   /* staging of csgpu_propagate_one */
   cs_val *d_one_in, *d_one_out;
@@ -131,8 +137,15 @@ static void free_device(csgpu_model *m) {
   (void)hipFree(m->d_tree_off); (void)hipFree(m->d_tnode); (void)hipFree(m->d_tkid); (void)hipFree(m->d_tree_want);
   m->d_tree_want = NULL;
   (void)hipFree(m->d_adj_packed);
+  (void)hipFree(m->d_root_lo);
+  (void)hipFree(m->d_sym_off);
+  (void)hipFree(m->d_sym_packed);
+  m->d_sym_off = NULL;
+  m->d_sym_packed = NULL;
   m->d_adj_packed = NULL;
+  m->d_root_lo = NULL;
   m->lds_waves = 0;
+  m->fb_words = 0;
   (void)hipFree(m->d_one_in); (void)hipFree(m->d_one_out); (void)hipFree(m->d_one_node); (void)hipFree(m->d_one_res);
   m->d_adj_off = m->d_adj = m->d_clause = m->d_tree_off = m->d_tnode = m->d_tkid = NULL;
   m->d_one_in = m->d_one_out = NULL;
@@ -346,6 +359,18 @@ static const void *ne_lds_kernel(int width, int n_vars) {
 #undef CS_PICK_U
 }
 
+static const void *ne_bitset_kernel(int width, int fw) {
+#define CS_PICK(E)                                                                                 \
+  switch (fw) {                                                                                    \
+  case 1: return (const void *)cs_propagate_ne_bitset<E, 1>;                                       \
+  case 2: return (const void *)cs_propagate_ne_bitset<E, 2>;                                       \
+  default: return (const void *)cs_propagate_ne_bitset<E, 4>;                                      \
+  }
+  if (width == 2) { CS_PICK(unsigned short) }
+  CS_PICK(unsigned int)
+#undef CS_PICK
+}
+
 /* ---- finalize ---------------------------------------------------------------------- */
 
 extern "C" int csgpu_model_build_tables(csgpu_model *m) {
@@ -450,6 +475,46 @@ extern "C" int csgpu_model_finalize(csgpu_model *m) {
     }
   }
 
+  /* forbidden-set kernel: additionally root intervals of at most 256 values, and only when the
+   * host domains really are the root state (the bit windows are anchored at the root bounds) */
+  m->fb_words = 0;
+  if (m->img->sym_width != 0 && !m->not_root) {
+    int64_t width = 1;
+    for (int32_t v = 0; v < h->n_vars; v++) {
+      const int64_t w = (int64_t)h->dom[v].hi - (int64_t)h->dom[v].lo + 1;
+      if (w > width) width = w;
+    }
+    const int fw = width <= 64 ? 1 : (width <= 128 ? 2 : (width <= 256 ? 4 : 0));
+    if (fw) {
+      const size_t off_bytes = (((size_t)h->n_vars * 2 * sizeof(int)) + 15) & ~(size_t)15;
+      const size_t base_bytes = (((size_t)h->n_vars * sizeof(int)) + 15) & ~(size_t)15;
+      const size_t adj_bytes = (((size_t)m->img->sym_n_adj * (size_t)m->img->sym_width) + 15) & ~(size_t)15;
+      const size_t sl = ((size_t)h->n_vars * sizeof(cs_val) + (size_t)h->n_vars * fw * 8 +
+                         (2 * (size_t)m->tab.n_words + 2) * sizeof(unsigned) + 15) & ~(size_t)15;
+      for (int waves = 16; waves >= 4; waves >>= 1) {
+        const size_t need = off_bytes + base_bytes + adj_bytes + (size_t)waves * sl;
+        if (need <= 160u * 1024u) {
+          m->fb_words = fw;
+          m->fb_waves = waves;
+          m->fb_bytes = need;
+          break;
+        }
+      }
+    }
+    if (m->fb_words) {
+      int *lo = (int *)malloc((size_t)(h->n_vars ? h->n_vars : 1) * sizeof(int));
+      for (int32_t v = 0; v < h->n_vars; v++) lo[v] = h->dom[v].lo;
+      rc = upload(lo, (size_t)h->n_vars * sizeof(int), &m->d_root_lo);
+      free(lo);
+      if (rc) return rc;
+      if ((rc = upload(m->img->sym_off, ((size_t)h->n_vars + 1) * sizeof(int), &m->d_sym_off))) return rc;
+      if ((rc = upload(m->img->sym_packed, (size_t)m->img->sym_n_adj * (size_t)m->img->sym_width,
+                       (int **)&m->d_sym_packed)))
+        return rc;
+      if ((rc = lds_limit(m->fb_bytes, ne_bitset_kernel(m->img->sym_width, m->fb_words)))) return rc;
+    }
+  }
+
   int dev = 0;
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDevice(&dev));
@@ -466,12 +531,43 @@ extern "C" int csgpu_model_finalize(csgpu_model *m) {
 }
 
 extern "C" int csgpu_model_set_kernel(csgpu_model *m, int which) {
-  if (m == NULL || which < 0 || which > 2) return set_err(CSGPU_E_ARG, "bad argument");
-  if (which == 2) {
+  if (m == NULL || which < 0 || which > 3) return set_err(CSGPU_E_ARG, "bad argument");
+  if (which >= 2) {
     if (!m->finalized) return set_err(CSGPU_E_STATE, "model is not finalized");
-    if (!m->lds_waves) return set_err(CSGPU_E_LIMIT, "model does not qualify for the LDS-resident kernel");
+    if (which == 2 && !m->lds_waves) return set_err(CSGPU_E_LIMIT, "model does not qualify for the LDS-resident kernel");
+    if (which == 3 && !m->fb_words) return set_err(CSGPU_E_LIMIT, "model does not qualify for the forbidden-set kernel");
   }
   m->kernel_choice = which;
+  return CSGPU_OK;
+}
+
+extern "C" int csgpu_model_forbidden_words(const csgpu_model *m) { return m && m->finalized ? m->fb_words : 0; }
+
+extern "C" int csgpu_propagate_batch_fb(const csgpu_model *m, const csgpu_val *d_states_in, const uint64_t *d_forb_in,
+                                        const csgpu_node *d_nodes, csgpu_val *d_states_out, uint64_t *d_forb_out,
+                                        csgpu_result *d_results, int64_t batch, void *stream) {
+  if (m == NULL || d_states_in == NULL || d_nodes == NULL || d_states_out == NULL || d_results == NULL || batch < 0)
+    return set_err(CSGPU_E_ARG, "null argument");
+  if (!m->finalized) return set_err(CSGPU_E_STATE, "model is not finalized");
+  if (!m->fb_words) return set_err(CSGPU_E_LIMIT, "model does not qualify for the forbidden-set kernel");
+  if (batch == 0) return CSGPU_OK;
+  size_t wg_per_cu = (160u * 1024u) / m->fb_bytes;
+  if (wg_per_cu > (size_t)(32 / m->fb_waves)) wg_per_cu = (size_t)(32 / m->fb_waves);
+  if (wg_per_cu < 1) wg_per_cu = 1;
+  int64_t grid = (int64_t)m->n_cus * (int64_t)wg_per_cu;
+  const int64_t chunks = (batch + CS_CHUNK - 1) / CS_CHUNK;
+  const int64_t need = (chunks + m->fb_waves - 1) / m->fb_waves;
+  if (grid > need) grid = need;
+  cs_tables tab = m->tab;
+  tab.adj_off = m->d_sym_off; /* the symmetric lists */
+  const void *packed = m->d_sym_packed;
+  int n_adj = m->img->sym_n_adj, obits = m->img->sym_obits, dmin = m->img->sym_dmin;
+  const int *root_lo = m->d_root_lo;
+  long long nb = (long long)batch;
+  void *args[] = { &tab, &packed, &n_adj, &obits, &dmin, &root_lo, &d_states_in, &d_forb_in, &d_nodes,
+                   &d_states_out, &d_forb_out, &d_results, &nb };
+  HIP_TRY(hipLaunchKernel(ne_bitset_kernel(m->img->sym_width, m->fb_words), dim3((unsigned)grid),
+                          dim3((unsigned)(m->fb_waves * CS_WAVE)), args, m->fb_bytes, (hipStream_t)stream));
   return CSGPU_OK;
 }
 
@@ -516,13 +612,16 @@ extern "C" int csgpu_propagate_batch_obj(const csgpu_model *m, const csgpu_val *
     tab.obj_lo = obj_lo;
     tab.obj_hi = obj_hi;
   }
+  if (m->kernel_choice == 3 && tab.obj_var < 0)
+    return csgpu_propagate_batch_fb(m, d_states_in, NULL, d_nodes, d_states_out, NULL, d_results, batch, stream);
   if (csgpu_model_get_kernel(m) == 2 && tab.obj_var < 0) {
     /* persistent workgroups: as many as stay resident (LDS- and wave-slot-limited) */
     size_t wg_per_cu = (160u * 1024u) / m->lds_bytes;
     if (wg_per_cu > (size_t)(32 / m->lds_waves)) wg_per_cu = (size_t)(32 / m->lds_waves);
     if (wg_per_cu < 1) wg_per_cu = 1;
     int64_t grid = (int64_t)m->n_cus * (int64_t)wg_per_cu;
-    const int64_t need = (batch + m->lds_waves - 1) / m->lds_waves;
+    const int64_t chunks = (batch + CS_CHUNK - 1) / CS_CHUNK;
+    const int64_t need = (chunks + m->lds_waves - 1) / m->lds_waves;
     if (grid > need) grid = need;
     const dim3 blk((unsigned)(m->lds_waves * CS_WAVE));
     int n_adj = m->img->n_adj, obits = m->img->packed_obits, dmin = m->img->packed_dmin;

@@ -109,7 +109,7 @@ static int32_t emit_tree(tree_ctx *t, int32_t node) {
 
 void cs_dev_image_free(cs_dev_image *g) {
   if (g == NULL) return;
-  free(g->adj_off); free(g->adj); free(g->clause); free(g->tree_off); free(g->tnode); free(g->tkid); free(g->tree_want); free(g->adj_packed);
+  free(g->adj_off); free(g->adj); free(g->clause); free(g->tree_off); free(g->tnode); free(g->tkid); free(g->tree_want); free(g->adj_packed); free(g->sym_off); free(g->sym_packed);
   free(g);
 }
 
@@ -225,6 +225,49 @@ cs_dev_image *cs_dev_image_build(const cs_model *m, int with_lists, const unsign
     }
   } else {
     g->adj = (int32_t *)calloc(2, sizeof(int32_t));
+  }
+  if (with_lists && g->n_tree_clauses == 0 && g->n_ne > 0) {
+    /* symmetric lists straight from the clause records */
+    const int32_t n = m->n_vars;
+    int32_t *cnt = (int32_t *)calloc((size_t)n + 1, sizeof(int32_t));
+    int32_t dmin = 0, dmax = 0;
+    for (int32_t c = 0; c < g->n_clauses; c++) {
+      const int32_t *rec = &g->clause[4 * c];
+      if (rec[0] != CS_CL_NE) continue;
+      cnt[rec[1] + 1]++;
+      cnt[rec[2] + 1]++;
+      const int32_t d = rec[3] < 0 ? -rec[3] : rec[3];
+      if (d > dmax) dmax = d;
+    }
+    dmin = -dmax;
+    for (int32_t v = 0; v < n; v++) cnt[v + 1] += cnt[v];
+    int obits = 1, dbits = 1;
+    while ((1 << obits) < n) obits++;
+    while (((int64_t)1 << dbits) <= (int64_t)dmax - (int64_t)dmin) dbits++;
+    const int width = obits + dbits <= 16 ? 2 : (obits + dbits <= 32 ? 4 : 0);
+    if (width != 0) {
+      g->sym_n_adj = cnt[n];
+      g->sym_width = width;
+      g->sym_obits = obits;
+      g->sym_dmin = dmin;
+      g->sym_off = (int32_t *)malloc(((size_t)n + 1) * sizeof(int32_t));
+      memcpy(g->sym_off, cnt, ((size_t)n + 1) * sizeof(int32_t));
+      g->sym_packed = malloc((size_t)(cnt[n] ? cnt[n] : 1) * (size_t)width);
+      int32_t *fill = (int32_t *)malloc(((size_t)n + 1) * sizeof(int32_t));
+      memcpy(fill, cnt, ((size_t)n + 1) * sizeof(int32_t));
+      for (int32_t c = 0; c < g->n_clauses; c++) {
+        const int32_t *rec = &g->clause[4 * c];
+        if (rec[0] != CS_CL_NE) continue;
+        /* X_a != X_b + d: seen from a -> (b, d); seen from b -> (a, -d) */
+        const uint32_t ea = (uint32_t)rec[2] | ((uint32_t)(rec[3] - dmin) << obits);
+        const uint32_t eb = (uint32_t)rec[1] | ((uint32_t)(-rec[3] - dmin) << obits);
+        const int32_t ia = fill[rec[1]]++, ib = fill[rec[2]]++;
+        if (width == 2) { ((uint16_t *)g->sym_packed)[ia] = (uint16_t)ea; ((uint16_t *)g->sym_packed)[ib] = (uint16_t)eb; }
+        else { ((uint32_t *)g->sym_packed)[ia] = ea; ((uint32_t *)g->sym_packed)[ib] = eb; }
+      }
+      free(fill);
+    }
+    free(cnt);
   }
   return g;
 }

@@ -64,6 +64,13 @@ typedef struct cs_dev_image {
    * other | (d - packed_dmin) << packed_obits, 2 or 4 bytes wide (0 = not available) */
   int32_t packed_width, packed_obits, packed_dmin;
   void *adj_packed;     /* [n_adj] uint16_t or uint32_t */
+  /* symmetric adjacency for the forbidden-set kernel: every binary clause is listed under BOTH of
+   * its variables, also under one that was already a single value at the root (the reference gives
+   * such a variable no clause list, parser_support.c:341, because it can never change -- but its
+   * value must still reach the neighbours' forbidden sets) */
+  int32_t sym_n_adj, sym_width, sym_obits, sym_dmin;
+  int32_t *sym_off;     /* [n_vars+1] */
+  void *sym_packed;     /* [sym_n_adj] */
 } cs_dev_image;
 
 /* with_lists = 0: clause-centric view only (root phase, lists not needed).

@@ -613,6 +613,209 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_lds(cs
   }
 }
 
+/* ---- the hot kernel, forbidden-set variant for pure binary-NE networks --------------
+ *
+ * What the reference's propagators compute on a != network is, for every open variable, the
+ * interval between the lowest and the highest value that no VALUED neighbour forbids
+ * (propagate_eq_false_lr only fires when the other side is a single value sitting on a bound,
+ * propagate.c:106-120, and keeps firing until the bound is free).  This kernel keeps that
+ * "forbidden by a valued neighbour" set explicitly: FW 64-bit words per variable, bit k <=>
+ * value root_lo+k.  A round is
+ *   (1) every variable that has just become a value pushes its forbidden value into the sets of
+ *       all its neighbours (one LDS atomic OR per adjacency entry, no domain reads), then
+ *   (2) every variable (one lane each) re-derives its bounds from its set with two bit scans;
+ *       an empty set of allowed values is the inconsistency, a variable left with one value
+ *       is pushed in the next round.
+ * The fixpoint, the verdict and -- because every reference propagation on such a network removes
+ * exactly one value from one bound -- the PROPS count of a consistent node are those of the
+ * unit-shaving kernels above; the work per node drops from one list scan per narrowing to one
+ * list scan per NEWLY VALUED variable.
+ * The sets travel with the state (forb_in / forb_out, [rows][n][FW] u64): a child inherits its
+ * parent's sets, so nothing is rebuilt down a search path.  With forb_in == NULL the sets are
+ * rebuilt from the valued variables of the incoming state (one list scan per valued variable).
+ */
+template <typename E, int FW>
+__global__ __launch_bounds__(1024, (FW <= 1 ? 8 : 4)) void cs_propagate_ne_bitset(
+    cs_tables T, const E *__restrict__ adj_packed, int n_adj, int obits, int dmin, const int *__restrict__ root_lo,
+    const cs_val *__restrict__ states_in, const unsigned long long *__restrict__ forb_in,
+    const cs_node_in *__restrict__ nodes, cs_val *__restrict__ states_out, unsigned long long *__restrict__ forb_out,
+    cs_node_out *__restrict__ results, long long batch) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
+  typedef unsigned long long u64;
+  const int lane = threadIdx.x & (CS_WAVE - 1);
+  const int wave_in_block = threadIdx.x >> 6;
+  const int waves_per_block = blockDim.x >> 6;
+  const int n = T.n_vars, nw = T.n_words;
+  /* LDS: {begin,end}[n] | root_lo[n] | packed adjacency | per wave: domains, sets, two masks, counter */
+  int2 *s_off2 = (int2 *)cs_lds;
+  const size_t off_bytes = (((size_t)n * sizeof(int2)) + 15) & ~(size_t)15;
+  int *s_base = (int *)(cs_lds + off_bytes);
+  const size_t base_bytes = (((size_t)n * sizeof(int)) + 15) & ~(size_t)15;
+  E *s_adj = (E *)(cs_lds + off_bytes + base_bytes);
+  const size_t adj_bytes = (((size_t)n_adj * sizeof(E)) + 15) & ~(size_t)15;
+  const size_t slice = (size_t)n * sizeof(cs_val) + (size_t)n * FW * sizeof(u64) + (2 * (size_t)nw + 2) * sizeof(unsigned);
+  const size_t slice_al = (slice + 15) & ~(size_t)15;
+  unsigned char *mine = cs_lds + off_bytes + base_bytes + adj_bytes + wave_in_block * slice_al;
+  cs_val *dom = (cs_val *)mine;
+  u64 *forb = (u64 *)(dom + n);
+  unsigned *mask_a = (unsigned *)(forb + (size_t)n * FW);
+  unsigned *mask_b = mask_a + nw;
+
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    s_off2[i] = make_int2(T.adj_off[i], T.adj_off[i + 1]);
+    s_base[i] = root_lo[i];
+  }
+  for (int i = threadIdx.x; i < n_adj; i += blockDim.x) s_adj[i] = adj_packed[i];
+  __syncthreads();
+
+  const unsigned omask = (1u << obits) - 1u;
+  const long long chunks = (batch + CS_CHUNK - 1) / CS_CHUNK;
+  const long long waves_total = (long long)gridDim.x * waves_per_block;
+  for (long long chunk = (long long)blockIdx.x * waves_per_block + wave_in_block; chunk < chunks; chunk += waves_total) {
+    const long long base = chunk * CS_CHUNK;
+    const int cnt = (int)(batch - base < CS_CHUNK ? batch - base : CS_CHUNK);
+    cs_node_in rec;
+    rec.var = -1; rec.lo = 0; rec.hi = 0; rec.parent = 0;
+    if (lane < cnt) rec = nodes[base + lane];
+    cs_node_out my_result;
+    my_result.status = 0; my_result.props = 0; my_result.revisions = 0; my_result.rounds = 0;
+
+    for (int j = 0; j < cnt; j++) {
+      const int nvar = __builtin_amdgcn_readlane(rec.var, j);
+      const int nlo = __builtin_amdgcn_readlane(rec.lo, j), nhi = __builtin_amdgcn_readlane(rec.hi, j);
+      const size_t prow = (size_t)__builtin_amdgcn_readlane(rec.parent, j);
+      const cs_val *src = states_in + prow * n;
+      for (int v = lane; v < n; v += CS_WAVE) dom[v] = src[v];
+      if (forb_in != nullptr) {
+        const u64 *fsrc = forb_in + prow * n * FW;
+        for (int k = lane; k < n * FW; k += CS_WAVE) forb[k] = fsrc[k];
+      } else {
+        for (int k = lane; k < n * FW; k += CS_WAVE) forb[k] = 0ull;
+      }
+      for (int w = lane; w < nw; w += CS_WAVE) { mask_a[w] = 0u; mask_b[w] = 0u; }
+      cs_wave_sync();
+      /* the assignment (step_enter, csolve.c:294-304) and the first set of variables to push */
+      if (lane == 0 && nvar >= 0) dom[nvar] = cs_interval(nlo, nhi);
+      cs_wave_sync();
+      if (forb_in == nullptr || nvar < 0) {
+        /* no inherited sets: every valued variable of the incoming state pushes */
+        for (int base_v = 0; base_v < n; base_v += CS_WAVE) {
+          const int v = base_v + lane;
+          const cs_val d = v < n ? dom[v] : cs_interval(0, 1);
+          const u64 b = __ballot(d.lo == d.hi);
+          if (lane == 0) {
+            mask_a[base_v >> 5] = (unsigned)b;
+            if ((base_v >> 5) + 1 < nw) mask_a[(base_v >> 5) + 1] = (unsigned)(b >> 32);
+          }
+        }
+      } else if (lane == 0 && nlo == nhi) {
+        mask_a[nvar >> 5] = 1u << (nvar & 31);
+      }
+      cs_wave_sync();
+
+      unsigned *cur = mask_a, *nxt = mask_b;
+      int rounds = 0, failed = 0, revisions = 0, props = 0;
+      for (;;) {
+        /* (1) newly valued variables push their forbidden value into the neighbours' sets */
+        for (int w = 0; w < nw; w++) {
+          unsigned bits = __builtin_amdgcn_readfirstlane(cur[w]);
+          while (bits != 0u) {
+            const int u = w * 32 + __builtin_ctz(bits);
+            bits &= bits - 1u;
+            const int c = __builtin_amdgcn_readfirstlane(dom[u].lo);
+            const int2 range = s_off2[u];
+            const int beg = __builtin_amdgcn_readfirstlane(range.x), end = __builtin_amdgcn_readfirstlane(range.y);
+            revisions += end - beg;
+            for (int i = beg + lane; i < end; i += CS_WAVE) {
+              const unsigned e = s_adj[i];
+              const int wv = (int)(e & omask);
+              const int bit = c - ((int)(e >> obits) + dmin) - s_base[wv];
+              if ((unsigned)bit < (unsigned)(64 * FW)) atomicOr(&forb[wv * FW + (bit >> 6)], 1ull << (bit & 63));
+            }
+          }
+        }
+        cs_wave_sync();
+        for (int w = lane; w < nw; w += CS_WAVE) cur[w] = 0u;
+        /* (2) every variable re-derives its bounds from its set */
+        int fail = 0;
+        for (int base_v = 0; base_v < n; base_v += CS_WAVE) {
+          const int v = base_v + lane;
+          int newly = 0;
+          if (v < n) {
+            const cs_val d = dom[v];
+            const int b0 = s_base[v];
+            int lo = d.lo, hi = d.hi;
+            if (lo > hi) {
+              fail = 1;
+            } else {
+              /* allowed = values of [lo,hi] that are not forbidden; its lowest / highest member */
+              int nlo2 = 0x7fffffff, nhi2 = (int)0x80000000;
+#pragma unroll
+              for (int k = 0; k < FW; k++) {
+                const int wlo = b0 + 64 * k; /* value of bit 0 of word k */
+                int from = lo - wlo, to = hi - wlo;
+                if (to < 0 || from > 63) continue;
+                from = from < 0 ? 0 : from;
+                to = to > 63 ? 63 : to;
+                const u64 span = (to - from == 63) ? ~0ull : (((1ull << (to - from + 1)) - 1ull) << from);
+                const u64 allowed = ~forb[v * FW + k] & span;
+                if (allowed != 0ull) {
+                  const int first = wlo + __builtin_ctzll(allowed), last = wlo + 63 - __builtin_clzll(allowed);
+                  nlo2 = first < nlo2 ? first : nlo2;
+                  nhi2 = last > nhi2 ? last : nhi2;
+                }
+              }
+              if (nlo2 > nhi2) {
+                fail = 1;
+              } else if (nlo2 != lo || nhi2 != hi) {
+                props += (nlo2 - lo) + (hi - nhi2);
+                dom[v] = cs_interval(nlo2, nhi2);
+                newly = nlo2 == nhi2;
+              }
+            }
+          }
+          const u64 nb = __ballot(newly);
+          if (lane == 0 && nb != 0ull) {
+            nxt[base_v >> 5] |= (unsigned)nb;
+            if ((base_v >> 5) + 1 < nw) nxt[(base_v >> 5) + 1] |= (unsigned)(nb >> 32);
+          }
+        }
+        if (__any(fail)) { failed = 1; break; }
+        cs_wave_sync();
+        int more = 0;
+        for (int w = 0; w < nw; w++) more |= __builtin_amdgcn_readfirstlane(nxt[w]) != 0u;
+        if (!more) break;
+        rounds++;
+        unsigned *t = cur; cur = nxt; nxt = t;
+      }
+      cs_wave_sync();
+
+      for (int off = 32; off > 0; off >>= 1) props += __shfl_xor(props, off);
+      int open_vars = 0;
+      if (!failed) {
+        cs_val *dst = states_out + (size_t)(base + j) * n;
+        for (int v = lane; v < n; v += CS_WAVE) {
+          const cs_val d = dom[v];
+          dst[v] = d;
+          open_vars += __popcll(__ballot(d.lo != d.hi));
+        }
+        if (forb_out != nullptr) {
+          u64 *fdst = forb_out + (size_t)(base + j) * n * FW;
+          for (int k = lane; k < n * FW; k += CS_WAVE) fdst[k] = forb[k];
+        }
+      }
+      if (lane == j) {
+        my_result.status = failed ? -1 : open_vars;
+        my_result.props = props;
+        my_result.revisions = revisions;
+        my_result.rounds = rounds;
+      }
+      cs_wave_sync();
+    }
+    if (lane < cnt) results[base + lane] = my_result;
+  }
+}
+
 /* ---- full sweeps (root phase): one workgroup per instance ------------------------ */
 
 __global__ __launch_bounds__(CS_BLOCK) void cs_propagate_sweeps(cs_tables T, const cs_val *__restrict__ states_in,

@@ -159,6 +159,35 @@ class Model:
                                                    _stream_ptr(stream)))
         return states_out, results
 
+    def forbidden_words(self) -> int:
+        """64-bit words of forbidden-set per variable (0: the model does not qualify)"""
+        return load_library().csgpu_model_forbidden_words(self._h)
+
+    def propagate_fb(self, states_in, nodes, forb_in=None, states_out=None, forb_out=None, results=None,
+                     want_forb=True, stream=None):
+        """Batched propagate_clauses with the forbidden sets carried next to the states.
+        forb_in/forb_out: int64 tensors [rows, n_vars, FW] (None = rebuild / not wanted).
+        returns (states_out, forb_out, results)"""
+        n, fw = self.n_vars, self.forbidden_words()
+        assert fw > 0, "model does not qualify for the forbidden-set kernel"
+        assert states_in.is_cuda and states_in.dtype == torch.int32 and states_in.is_contiguous()
+        assert nodes.is_cuda and nodes.dtype == torch.int32 and nodes.is_contiguous()
+        B = nodes.shape[0]
+        if states_out is None:
+            states_out = torch.empty((B, n, 2), dtype=torch.int32, device=nodes.device)
+        if results is None:
+            results = torch.empty((B, 4), dtype=torch.int32, device=nodes.device)
+        if forb_out is None and want_forb:
+            forb_out = torch.empty((B, n, fw), dtype=torch.int64, device=nodes.device)
+        if forb_in is not None:
+            assert forb_in.dtype == torch.int64 and forb_in.is_contiguous() and forb_in.shape[-2:] == (n, fw)
+            assert forb_in.shape[0] == states_in.shape[0]
+        check(load_library().csgpu_propagate_batch_fb(
+            self._h, states_in.data_ptr(), 0 if forb_in is None else forb_in.data_ptr(), nodes.data_ptr(),
+            states_out.data_ptr(), 0 if forb_out is None else forb_out.data_ptr(), results.data_ptr(), B,
+            _stream_ptr(stream)))
+        return states_out, forb_out, results
+
     def eval_root(self, states: torch.Tensor, stream=None) -> torch.Tensor:
         """Three-valued value of the root wide-and per state: 1 true, 0 false, 2 undecided."""
         assert states.is_cuda and states.dtype == torch.int32 and states.is_contiguous()

@@ -112,11 +112,13 @@ int csgpu_model_build_tables(csgpu_model *m);
 int csgpu_model_finalize(csgpu_model *m);
 
 /* Kernel selection for the batched fixpoint: 0 = automatic (default), 1 = the general kernel
- * (adjacency read through L2; handles tree clauses), 2 = the LDS-resident kernel (pure binary-NE
- * models whose packed adjacency fits in LDS; CSGPU_E_LIMIT if the model does not qualify).
- * Both compute the same results; tests run every parity case through each of them. */
+ * (adjacency read through L2; handles tree clauses), 2 = the LDS-resident unit-shaving kernel
+ * (pure binary-NE models whose packed adjacency fits in LDS), 3 = the forbidden-set kernel (same
+ * models, root intervals of at most 256 values); CSGPU_E_LIMIT if the model does not qualify.
+ * All compute the same results; tests run every parity case through each of them.  Automatic:
+ * 3 when forbidden-set buffers are passed (csgpu_propagate_batch_fb), else 2, else 1. */
 int csgpu_model_set_kernel(csgpu_model *m, int which);
-/* which kernel csgpu_propagate_batch will launch: 1 or 2 (see above) */
+/* which kernel csgpu_propagate_batch will launch: 1, 2 or 3 (see above) */
 int csgpu_model_get_kernel(const csgpu_model *m);
 
 /* ---- batched propagation (the hot path) ----
@@ -136,6 +138,18 @@ int csgpu_propagate_batch(const csgpu_model *m, const csgpu_val *d_states_in, co
 int csgpu_propagate_batch_obj(const csgpu_model *m, const csgpu_val *d_states_in, const csgpu_node *d_nodes,
                               csgpu_val *d_states_out, csgpu_result *d_results, int64_t batch, int32_t obj_lo,
                               int32_t obj_hi, void *stream);
+
+/* Forbidden-set variant (pure binary-NE models with root intervals of at most 256 values).
+ * Besides its interval every variable carries FW = csgpu_model_forbidden_words(m) 64-bit words:
+ * bit k set <=> value root_lo+k is forbidden by a neighbour that is a single value.  The sets are
+ * derived data that the search keeps next to each state so that a child inherits them:
+ *   d_forb_in  [*][n_vars][FW] uint64, rows parallel to d_states_in  (NULL: rebuild from the state)
+ *   d_forb_out [batch][n_vars][FW] uint64, rows parallel to d_states_out (NULL: not wanted)
+ * Results (fixpoints, verdicts, PROPS of consistent nodes) are those of csgpu_propagate_batch. */
+int csgpu_model_forbidden_words(const csgpu_model *m); /* 0: the model does not qualify */
+int csgpu_propagate_batch_fb(const csgpu_model *m, const csgpu_val *d_states_in, const uint64_t *d_forb_in,
+                             const csgpu_node *d_nodes, csgpu_val *d_states_out, uint64_t *d_forb_out,
+                             csgpu_result *d_results, int64_t batch, void *stream);
 
 /* Three-valued evaluation of the root wide-and for a batch of states:
  * d_truth[i] = 1 (all clauses true), 0 (some clause false), 2 (undecided). */

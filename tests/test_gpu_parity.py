@@ -20,7 +20,12 @@ WALKS_WITH_MODEL = sorted(os.path.basename(p)[:-8] for p in glob.glob(golden("wa
 
 def _kernels(model):
     """every kernel that can run this model: 1 = general, 2 = LDS-resident (when it qualifies)"""
-    return [1, 2] if model.kernel() == 2 else [1]
+    ks = [1]
+    if model.kernel() == 2:
+        ks.append(2)
+    if model.forbidden_words() > 0:
+        ks.append(3)  # forbidden-set kernel, sets rebuilt from the incoming state
+    return ks
 
 
 def _gpu_walk(model, walk):
@@ -113,8 +118,9 @@ def _random_nodes(rng, states, count):
     return nodes
 
 
-@pytest.mark.parametrize("kind,size,kernel", [("queens", 64, 1), ("queens", 64, 2), ("queens", 128, 1),
-                                              ("queens", 128, 2), ("sudoku", 5, 1), ("sudoku", 5, 2),
+@pytest.mark.parametrize("kind,size,kernel", [("queens", 64, 1), ("queens", 64, 2), ("queens", 64, 3),
+                                              ("queens", 128, 1), ("queens", 128, 2), ("queens", 128, 3),
+                                              ("sudoku", 5, 1), ("sudoku", 5, 2), ("sudoku", 5, 3),
                                               ("schedule", 16, 1)])
 def test_batch_vs_oracle_and_properties(kind, size, kernel):
     """Seeded multi-level batches at the BASELINE sizes: a sample is checked against the oracle
@@ -129,6 +135,8 @@ def test_batch_vs_oracle_and_properties(kind, size, kernel):
     model = solve_root(text)
     model.set_kernel(kernel)
     assert model.kernel() == kernel
+    if kernel == 3:
+        assert model.forbidden_words() == {("queens", 64): 1, ("queens", 128): 2, ("sudoku", 5): 1}[(kind, size)]
     n = model.n_vars
     omodel = OModel.parse(text)
     omodel.set_domains(model.domains())
@@ -212,3 +220,62 @@ def test_propagate_one_host_path():
         else:
             assert st == int((out[:, 0] != out[:, 1]).sum()) and props == walk["status"][i]
             assert (out == walk["after"][i]).all()
+
+
+@pytest.mark.parametrize("kind,size", [("queens", 16), ("queens", 64), ("queens", 128), ("sudoku", 3), ("sudoku", 5)])
+def test_forbidden_sets_inherited_down_a_path(kind, size):
+    """The forbidden-set kernel with the sets carried from parent to child (the search engine's
+    mode) against the general kernel and the oracle, five levels deep: same verdicts, same
+    domains, same PROPS; and the carried sets equal the sets rebuilt from scratch."""
+    from csolve_amd import problems
+    from csolve_amd.solver import solve_root
+    from oracle.cs_oracle import Model as OModel, Oracle
+    text = problems.queens(size) if kind == "queens" else problems.sudoku(size, 0.4, 1)
+    model = solve_root(text)
+    fw = model.forbidden_words()
+    assert fw > 0
+    n = model.n_vars
+    omodel = OModel.parse(text)
+    omodel.set_domains(model.domains())
+    omodel.index()
+    orc = Oracle(omodel)
+    rng = np.random.default_rng(7)
+    root = model.root_state()
+    full = torch.tensor([[-1, 0, 0, 0]], dtype=torch.int32, device="cuda")
+    states, forb, res = model.propagate_fb(root, full)  # root sets
+    torch.cuda.synchronize()
+    assert int(res[0, 0]) >= 0 and int(res[0, 1]) == 0 and torch.equal(states, root)
+    states_h = states.cpu().numpy()
+    for level in range(5):
+        nodes = _random_nodes(rng, states_h, 768)
+        d_nodes = torch.from_numpy(nodes).cuda()
+        out3, forb3, res3 = model.propagate_fb(states, d_nodes, forb_in=forb)
+        model.set_kernel(1)
+        out1, res1 = model.propagate(states, d_nodes)
+        model.set_kernel(0)
+        torch.cuda.synchronize()
+        ok = res1[:, 0] >= 0
+        assert torch.equal(res3[:, 0] >= 0, ok)
+        assert torch.equal(out3[ok], out1[ok])
+        assert torch.equal(res3[ok][:, :2], res1[ok][:, :2])  # status (open variables) and PROPS
+        # oracle on a sample
+        sample = rng.choice(len(nodes), size=96, replace=False)
+        st, exp = orc.instances(states_h[nodes[sample, 3]], nodes[sample, 0], nodes[sample, 1])
+        r3 = res3.cpu().numpy()
+        assert ((st < 0) == (r3[sample, 0] < 0)).all()
+        good = sample[st >= 0]
+        assert (out3.cpu().numpy()[good] == exp[st >= 0]).all() and (r3[good, 1] == st[st >= 0]).all()
+        # the inherited sets are the sets one would rebuild from the child state
+        idx = torch.nonzero(ok)[:256, 0]
+        sub = out3[idx].contiguous()
+        again = torch.stack([torch.full((len(idx),), -1), torch.zeros(len(idx)), torch.zeros(len(idx)),
+                             torch.arange(len(idx))], 1).to(torch.int32).cuda()
+        s2, f2, r2 = model.propagate_fb(sub, again)
+        torch.cuda.synchronize()
+        assert torch.equal(s2, sub) and (r2[:, 1] == 0).all()
+        assert torch.equal(f2, forb3[idx])
+        keep = idx[:128]
+        states, forb = out3[keep].contiguous(), forb3[keep].contiguous()
+        states_h = states.cpu().numpy()
+        if len(keep) == 0:
+            break

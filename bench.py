@@ -39,6 +39,22 @@ from csolve_amd.solver import solve_root  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def measured_traffic(kernel_name, n_q, instances):
+    """HBM bytes per launch from the committed PMC profile of this very kernel and workload
+    (profiles/*_pmc_*.json, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in their own passes, FETCH_SIZE
+    doubled as MI355X_MICROARCH.md prescribes for gfx950), or None when there is no such profile."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_*.json")), reverse=True):
+        try:
+            rec = json.load(open(path))
+        except Exception:
+            continue
+        if kernel_name in rec.get("kernel", "") and f"queens-{n_q} " in rec.get("workload", "") and \
+                f"{instances} instances" in rec.get("workload", "") and "hbm_traffic_bytes_per_launch" in rec:
+            return rec["hbm_traffic_bytes_per_launch"]
+    return None
+
+
 def make_instances(model, count, seed, walks=8192, with_sets=False):
     """Seeded random walks on the device path.
     -> states_in [count,n,2], nodes [count,4], forb_in [count,n,FW] or None   (all on the device)"""
@@ -350,7 +366,7 @@ def main():
                    "inconsistent_fraction": fails_all / nodes_all,
                    "props_per_node": props_all / nodes_all, "revisions_per_node": revs_all / nodes_all},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(kernel_name, n_q, B),
                      "kernel": kernel_name, "kernel_ms": kernel_ms,
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "hbm_stream_bytes_per_launch": stream_bytes,

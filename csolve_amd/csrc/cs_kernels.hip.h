@@ -601,6 +601,7 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_lds(cs
           open_vars += __popcll(__ballot(d.lo != d.hi));
         }
       }
+      open_vars = __builtin_amdgcn_readfirstlane(open_vars); /* lanes >= n_vars never ran the loop */
       if (lane == j) { /* lane j keeps node j's result; one coalesced store per chunk */
         my_result.status = failed ? -1 : open_vars;
         my_result.props = props;
@@ -804,6 +805,7 @@ __global__ __launch_bounds__(1024, (FW <= 1 ? 8 : 4)) void cs_propagate_ne_bitse
           for (int k = lane; k < n * FW; k += CS_WAVE) fdst[k] = forb[k];
         }
       }
+      open_vars = __builtin_amdgcn_readfirstlane(open_vars); /* lanes >= n_vars never ran the loop */
       if (lane == j) {
         my_result.status = failed ? -1 : open_vars;
         my_result.props = props;

@@ -6,7 +6,7 @@ for d in sorted(glob.glob(pat+'*/runc/*_counter_collection.csv')):
     per=collections.defaultdict(dict)
     for r in rows:
         dur=(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3
-        if 'cs_propagate_ne_lds' in r['Kernel_Name'] or 'cs_propagate_events' in r['Kernel_Name']:
+        if 'cs_propagate_' in r['Kernel_Name'] and 'sweeps' not in r['Kernel_Name']:
             if dur>=minus: per[r['Dispatch_Id']][r['Counter_Name']]=float(r['Counter_Value']); per[r['Dispatch_Id']]['_dur_us']=dur
     keys=set(k for v in per.values() for k in v)
     for k in keys:

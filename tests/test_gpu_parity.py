@@ -54,6 +54,7 @@ def test_reference_walks_on_reference_model(name):
         assert ((res[:, 0] < 0) == fail_ref).all()
         ok = ~fail_ref
         assert (out[ok] == walk["after"][ok]).all()
+        assert (res[ok, 0] == (out[ok, :, 0] != out[ok, :, 1]).sum(1)).all()  # status = open variables
         if name in NE_ONLY:
             assert (res[ok, 1] == walk["status"][ok]).all()
 

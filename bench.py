@@ -55,27 +55,25 @@ def measured_traffic(kernel_name, n_q, instances):
     return None
 
 
-def make_instances(model, count, seed, walks=8192, with_sets=False):
-    """Seeded random walks on the device path.
-    -> states_in [count,n,2], nodes [count,4], forb_in [count,n,FW] or None   (all on the device)"""
+def make_instances(model, count, seed, walks=8192, with_sets=False, restore_kernel=0):
+    """Seeded random walks on the device path (untimed setup).
+    -> states_in [count,n,2], nodes [count,4], forb_in [count,n,FW] or None   (all on the device)
+    The walks run through the general kernel so that the profile of the timed kernel only contains
+    the full-size launches; the forbidden sets of the collected states are then produced by ONE
+    full-size launch of the forbidden-set kernel in rebuild mode (tests show they equal the sets a
+    search would have carried down to these states)."""
     n = model.n_vars
     root = model.domains()
     rng = np.random.default_rng(seed)
     walks = min(walks, count)
     cur = np.repeat(root[None], walks, 0)
-    root_forb = cur_forb = None
-    if with_sets:
-        full = torch.tensor([[-1, 0, 0, 0]], dtype=torch.int32, device="cuda")
-        _, root_forb, _ = model.propagate_fb(model.root_state(), full)
-        cur_forb = root_forb.repeat(walks, 1, 1).contiguous()
-    states, nodes, forbs = [], [], []
+    model.set_kernel(1)
+    states, nodes = [], []
     have = 0
     while have < count:
         open_mask = cur[:, :, 0] < cur[:, :, 1]
         done = ~open_mask.any(1)
         cur[done] = root
-        if with_sets and done.any():
-            cur_forb[torch.from_numpy(done).cuda()] = root_forb[0]
         open_mask[done] = root[:, 0] < root[:, 1]
         # random open variable per walk, random value of its interval
         keys = rng.random(open_mask.shape)
@@ -86,28 +84,29 @@ def make_instances(model, count, seed, walks=8192, with_sets=False):
         val = lo + (rng.random(walks) * (hi - lo + 1)).astype(np.int64).clip(0, hi - lo)
         nd = np.stack([var, val, val, np.arange(walks)], 1).astype(np.int32)
         d_cur = torch.from_numpy(cur).cuda()
-        if with_sets:
-            out, fout, res = model.propagate_fb(d_cur, torch.from_numpy(nd).cuda(), forb_in=cur_forb)
-        else:
-            out, res = model.propagate(d_cur, torch.from_numpy(nd).cuda())
+        out, res = model.propagate(d_cur, torch.from_numpy(nd).cuda())
         torch.cuda.synchronize()
         take = min(walks, count - have)
         states.append(d_cur[:take].clone())
-        if with_sets:
-            forbs.append(cur_forb[:take].clone())
         nd_take = nd[:take].copy()
         nd_take[:, 3] = np.arange(have, have + take)
         nodes.append(torch.from_numpy(nd_take).cuda())
         have += take
-        okt = res[:, 0] >= 0
-        ok = okt.cpu().numpy()
+        ok = (res[:, 0] >= 0).cpu().numpy()
         nxt = out.cpu().numpy()
         nxt[~ok] = root
         cur = nxt
-        if with_sets:
-            cur_forb = torch.where(okt[:, None, None], fout, root_forb.expand_as(fout)).contiguous()
-    return (torch.cat(states).contiguous(), torch.cat(nodes).contiguous(),
-            torch.cat(forbs).contiguous() if with_sets else None)
+    model.set_kernel(restore_kernel)
+    states_in, nodes = torch.cat(states).contiguous(), torch.cat(nodes).contiguous()
+    forb_in = None
+    if with_sets:
+        rebuild = torch.zeros((count, 4), dtype=torch.int32, device="cuda")
+        rebuild[:, 0] = -1
+        rebuild[:, 3] = torch.arange(count, dtype=torch.int32, device="cuda")
+        same, forb_in, res = model.propagate_fb(states_in, rebuild)
+        torch.cuda.synchronize()
+        assert torch.equal(same, states_in) and bool((res[:, 1] == 0).all())
+    return states_in, nodes, forb_in
 
 
 REF_BIN = os.path.join(ROOT, "oracle", "_ref", "csolve_ref")
@@ -290,14 +289,15 @@ def main():
     # 1 general, 2 LDS-resident unit shaving, 3 forbidden-set kernel
     fw = model.forbidden_words()
     use_sets = fw > 0 and args.kernel in (0, 3) and not args.rebuild_sets
-    if args.kernel in (1, 2) or (args.kernel == 3 and not use_sets):
-        model.set_kernel(args.kernel)
+    forced = args.kernel if (args.kernel in (1, 2) or (args.kernel == 3 and not use_sets)) else 0
+    model.set_kernel(forced)
     kernel_name = "cs_propagate_ne_bitset" if (use_sets or args.kernel == 3) else \
         {1: "cs_propagate_events", 2: "cs_propagate_ne_lds", 3: "cs_propagate_ne_bitset"}[model.kernel()]
     n = model.n_vars
     info = model.device_info()
 
-    states_in, nodes, forb_in = make_instances(model, args.instances, seed=12345 + rank, with_sets=use_sets)
+    states_in, nodes, forb_in = make_instances(model, args.instances, seed=12345 + rank, with_sets=use_sets,
+                                               restore_kernel=forced)
     B = nodes.shape[0]
     states_out = torch.empty((B, n, 2), dtype=torch.int32, device="cuda")
     results = torch.empty((B, 4), dtype=torch.int32, device="cuda")

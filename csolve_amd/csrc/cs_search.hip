@@ -25,6 +25,10 @@ struct csgpu_search {
   int64_t cap, max_children, max_parents, max_width;
   cs_val *pool;
   int64_t top, peak;
+  /* forbidden sets travelling with the states (pure binary-NE models, csgpu_propagate_batch_fb) */
+  int fw;
+  unsigned long long *pool_forb, *d_child_forb;
+  csgpu_node *d_rebuild_nodes;
   int *d_branch_var, *d_child_count, *d_child_off;
   csgpu_node *d_nodes;
   cs_val *d_child_states, *d_complete_states;
@@ -202,7 +206,9 @@ __global__ __launch_bounds__(SB) void cs_select(const csgpu_result *__restrict__
 
 /* one wave per child: copy survivors into their pool rows */
 __global__ __launch_bounds__(SB) void cs_scatter(const cs_val *__restrict__ child_states, const int *__restrict__ dest,
-                                                 int children, int n, cs_val *__restrict__ pool) {
+                                                 int children, int n, cs_val *__restrict__ pool,
+                                                 const unsigned long long *__restrict__ child_forb,
+                                                 unsigned long long *__restrict__ pool_forb, int fw) {
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * (SB / 64) + (threadIdx.x >> 6);
   if (i >= children) return;
@@ -211,6 +217,20 @@ __global__ __launch_bounds__(SB) void cs_scatter(const cs_val *__restrict__ chil
   const cs_val *src = child_states + (size_t)i * n;
   cs_val *dst = pool + (size_t)d * n;
   for (int v = lane; v < n; v += 64) dst[v] = src[v];
+  if (fw > 0) {
+    const unsigned long long *fs = child_forb + (size_t)i * n * fw;
+    unsigned long long *fd = pool_forb + (size_t)d * n * fw;
+    for (int k = lane; k < n * fw; k += 64) fd[k] = fs[k];
+  }
+}
+
+/* nodes {-1,0,0,row}: "rebuild the forbidden sets of this state" */
+__global__ void cs_fill_rebuild(csgpu_node *__restrict__ nodes, long long first_row, int count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  csgpu_node nd;
+  nd.var = -1; nd.lo = 0; nd.hi = 0; nd.parent = (int)(first_row + i);
+  nodes[i] = nd;
 }
 
 /* one wave per complete child: gather it for the root evaluation */
@@ -247,18 +267,19 @@ __global__ __launch_bounds__(SB) void cs_accept(const cs_val *__restrict__ compl
 }
 
 /* move the newest `count` rows into the hole left by taking the oldest ones */
-__global__ __launch_bounds__(SB) void cs_move_rows(cs_val *__restrict__ pool, long long src_row, long long dst_row,
-                                                   int count, int n) {
+__global__ __launch_bounds__(SB) void cs_move_rows(unsigned long long *__restrict__ pool, long long src_row,
+                                                   long long dst_row, int count, int words_per_row) {
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * (SB / 64) + (threadIdx.x >> 6);
   if (i >= count) return;
-  const cs_val *src = pool + (size_t)(src_row + i) * n;
-  cs_val *dst = pool + (size_t)(dst_row + i) * n;
-  for (int v = lane; v < n; v += 64) dst[v] = src[v];
+  const unsigned long long *src = pool + (size_t)(src_row + i) * words_per_row;
+  unsigned long long *dst = pool + (size_t)(dst_row + i) * words_per_row;
+  for (int v = lane; v < words_per_row; v += 64) dst[v] = src[v];
 }
 
 extern "C" void csgpu_search_free(csgpu_search *s) {
   if (s == NULL) return;
+  (void)hipFree(s->pool_forb); (void)hipFree(s->d_child_forb); (void)hipFree(s->d_rebuild_nodes);
   (void)hipFree(s->pool); (void)hipFree(s->d_branch_var); (void)hipFree(s->d_child_count); (void)hipFree(s->d_child_off);
   (void)hipFree(s->d_nodes); (void)hipFree(s->d_child_states); (void)hipFree(s->d_complete_states);
   (void)hipFree(s->d_results); (void)hipFree(s->d_dest); (void)hipFree(s->d_complete_list); (void)hipFree(s->d_truth);
@@ -306,6 +327,12 @@ extern "C" int csgpu_search_create(const csgpu_model *m, int64_t pool_capacity, 
     return fail(CSGPU_E_HIP, hipGetErrorString(e));                            \
   }
   ALLOC(s->pool, row * (size_t)s->cap);
+  s->fw = s->obj_var < 0 ? csgpu_model_forbidden_words(m) : 0;
+  if (s->fw > 0) {
+    ALLOC(s->pool_forb, (size_t)n * s->fw * 8 * (size_t)s->cap);
+    ALLOC(s->d_child_forb, (size_t)n * s->fw * 8 * (size_t)max_children);
+    ALLOC(s->d_rebuild_nodes, sizeof(csgpu_node) * (size_t)max_children);
+  }
   ALLOC(s->d_branch_var, sizeof(int) * (size_t)s->max_parents);
   ALLOC(s->d_child_count, sizeof(int) * (size_t)s->max_parents);
   ALLOC(s->d_child_off, sizeof(int) * ((size_t)s->max_parents + 1));
@@ -332,6 +359,21 @@ extern "C" int csgpu_search_put(csgpu_search *s, const csgpu_val *d_states, int6
   if (count > 0)
     HIP_OK(hipMemcpy(s->pool + (size_t)s->top * s->n, d_states, (size_t)count * s->n * sizeof(cs_val),
                      hipMemcpyDeviceToDevice));
+  if (count > 0 && s->fw > 0) {
+    /* states arriving from outside (the root, another rank) carry no sets: rebuild them in place,
+     * max_children rows at a time (the batch buffers are free between iterations) */
+    for (int64_t done = 0; done < count; done += s->max_children) {
+      const int64_t k = count - done < s->max_children ? count - done : s->max_children;
+      hipLaunchKernelGGL(cs_fill_rebuild, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, 0, s->d_rebuild_nodes,
+                         (long long)(s->top + done), (int)k);
+      int rc = csgpu_propagate_batch_fb(s->m, (const csgpu_val *)s->pool, NULL, s->d_rebuild_nodes,
+                                        (csgpu_val *)s->d_child_states, (uint64_t *)s->d_child_forb, s->d_results, k,
+                                        NULL);
+      if (rc != CSGPU_OK) return rc;
+      HIP_OK(hipMemcpy(s->pool_forb + (size_t)(s->top + done) * s->n * s->fw, s->d_child_forb,
+                       (size_t)k * s->n * s->fw * 8, hipMemcpyDeviceToDevice));
+    }
+  }
   s->top += count;
   if (s->top > s->peak) s->peak = s->top;
   return CSGPU_OK;
@@ -346,8 +388,11 @@ extern "C" int csgpu_search_take(csgpu_search *s, csgpu_val *d_states, int64_t m
   /* fill the hole at the bottom with the newest rows */
   const int64_t rest = s->top - k, mv = rest < k ? rest : k;
   if (mv > 0) {
-    hipLaunchKernelGGL(cs_move_rows, dim3((unsigned)((mv + 3) / 4)), dim3(SB), 0, 0, s->pool, (long long)(s->top - mv),
-                       0ll, (int)mv, s->n);
+    hipLaunchKernelGGL(cs_move_rows, dim3((unsigned)((mv + 3) / 4)), dim3(SB), 0, 0, (unsigned long long *)s->pool,
+                       (long long)(s->top - mv), 0ll, (int)mv, s->n);
+    if (s->fw > 0)
+      hipLaunchKernelGGL(cs_move_rows, dim3((unsigned)((mv + 3) / 4)), dim3(SB), 0, 0, s->pool_forb,
+                         (long long)(s->top - mv), 0ll, (int)mv, s->n * s->fw);
     HIP_OK(hipGetLastError());
     HIP_OK(hipDeviceSynchronize());
   }
@@ -394,13 +439,20 @@ static int one_iteration(csgpu_search *s) {
   int32_t obj_lo = CS_DOM_MIN, obj_hi = CS_DOM_MAX;
   if (s->objective == CS_OBJ_MIN) obj_hi = cs_add(s->st.best, cs_neg(1));
   if (s->objective == CS_OBJ_MAX) obj_lo = cs_add(s->st.best, 1);
-  int rc = csgpu_propagate_batch_obj(s->m, (const csgpu_val *)s->pool, s->d_nodes, (csgpu_val *)s->d_child_states,
-                                     s->d_results, children, obj_lo, obj_hi, NULL);
+  int rc;
+  if (s->fw > 0)
+    rc = csgpu_propagate_batch_fb(s->m, (const csgpu_val *)s->pool, (const uint64_t *)s->pool_forb, s->d_nodes,
+                                  (csgpu_val *)s->d_child_states, (uint64_t *)s->d_child_forb, s->d_results, children,
+                                  NULL);
+  else
+    rc = csgpu_propagate_batch_obj(s->m, (const csgpu_val *)s->pool, s->d_nodes, (csgpu_val *)s->d_child_states,
+                                   s->d_results, children, obj_lo, obj_hi, NULL);
   if (rc != CSGPU_OK) return rc;
   const unsigned cb = (unsigned)((children + SB - 1) / SB), cw = (unsigned)((children + 3) / 4);
   hipLaunchKernelGGL(cs_select, dim3(cb), dim3(SB), 0, 0, s->d_results, (int)children, (long long)s->top, s->d_dest,
                      s->d_complete_list, s->d_counters);
-  hipLaunchKernelGGL(cs_scatter, dim3(cw), dim3(SB), 0, 0, s->d_child_states, s->d_dest, (int)children, n, s->pool);
+  hipLaunchKernelGGL(cs_scatter, dim3(cw), dim3(SB), 0, 0, s->d_child_states, s->d_dest, (int)children, n, s->pool,
+                     s->d_child_forb, s->pool_forb, s->fw);
   unsigned long long c[C_COUNT];
   HIP_OK(hipMemcpy(c, s->d_counters, sizeof c, hipMemcpyDeviceToHost));
   s->top += (int64_t)c[C_SURVIVORS];

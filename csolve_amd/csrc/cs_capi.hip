@@ -359,16 +359,28 @@ static const void *ne_lds_kernel(int width, int n_vars) {
 #undef CS_PICK_U
 }
 
-static const void *ne_bitset_kernel(int width, int fw) {
+static const void *ne_bitset_kernel(int width, int fw, int n_vars) {
+  /* prefetch depth R = ceil(n_vars/64) when that is 1, 2 or 4 (states of up to 256 variables) */
+  const int chunks = (n_vars + CS_WAVE - 1) / CS_WAVE;
+  int r = chunks <= 1 ? 1 : (chunks <= 2 ? 2 : (chunks <= 4 ? 4 : 0));
+  if (getenv("CSGPU_NO_PREFETCH") != NULL) r = 0;
+#define CS_PICK_R(E, F)                                                                            \
+  switch (r) {                                                                                     \
+  case 1: return (const void *)cs_propagate_ne_bitset<E, F, 1>;                                    \
+  case 2: return (const void *)cs_propagate_ne_bitset<E, F, 2>;                                    \
+  case 4: return (const void *)cs_propagate_ne_bitset<E, F, 4>;                                    \
+  default: return (const void *)cs_propagate_ne_bitset<E, F, 0>;                                   \
+  }
 #define CS_PICK(E)                                                                                 \
   switch (fw) {                                                                                    \
-  case 1: return (const void *)cs_propagate_ne_bitset<E, 1>;                                       \
-  case 2: return (const void *)cs_propagate_ne_bitset<E, 2>;                                       \
-  default: return (const void *)cs_propagate_ne_bitset<E, 4>;                                      \
+  case 1: CS_PICK_R(E, 1)                                                                          \
+  case 2: CS_PICK_R(E, 2)                                                                          \
+  default: CS_PICK_R(E, 4)                                                                         \
   }
   if (width == 2) { CS_PICK(unsigned short) }
   CS_PICK(unsigned int)
 #undef CS_PICK
+#undef CS_PICK_R
 }
 
 /* ---- finalize ---------------------------------------------------------------------- */
@@ -511,7 +523,7 @@ extern "C" int csgpu_model_finalize(csgpu_model *m) {
       if ((rc = upload(m->img->sym_packed, (size_t)m->img->sym_n_adj * (size_t)m->img->sym_width,
                        (int **)&m->d_sym_packed)))
         return rc;
-      if ((rc = lds_limit(m->fb_bytes, ne_bitset_kernel(m->img->sym_width, m->fb_words)))) return rc;
+      if ((rc = lds_limit(m->fb_bytes, ne_bitset_kernel(m->img->sym_width, m->fb_words, m->host->n_vars)))) return rc;
     }
   }
 
@@ -566,7 +578,7 @@ extern "C" int csgpu_propagate_batch_fb(const csgpu_model *m, const csgpu_val *d
   long long nb = (long long)batch;
   void *args[] = { &tab, &packed, &n_adj, &obits, &dmin, &root_lo, &d_states_in, &d_forb_in, &d_nodes,
                    &d_states_out, &d_forb_out, &d_results, &nb };
-  HIP_TRY(hipLaunchKernel(ne_bitset_kernel(m->img->sym_width, m->fb_words), dim3((unsigned)grid),
+  HIP_TRY(hipLaunchKernel(ne_bitset_kernel(m->img->sym_width, m->fb_words, m->host->n_vars), dim3((unsigned)grid),
                           dim3((unsigned)(m->fb_waves * CS_WAVE)), args, m->fb_bytes, (hipStream_t)stream));
   return CSGPU_OK;
 }

@@ -635,8 +635,8 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_lds(cs
  * parent's sets, so nothing is rebuilt down a search path.  With forb_in == NULL the sets are
  * rebuilt from the valued variables of the incoming state (one list scan per valued variable).
  */
-template <typename E, int FW>
-__global__ __launch_bounds__(1024, (FW <= 1 ? 8 : 4)) void cs_propagate_ne_bitset(
+template <typename E, int FW, int R> /* R = ceil(n_vars/64) for the prefetch pipeline, 0 = none */
+__global__ __launch_bounds__(1024, (FW <= 1 && R <= 1 ? 8 : 4)) void cs_propagate_ne_bitset(
     cs_tables T, const E *__restrict__ adj_packed, int n_adj, int obits, int dmin, const int *__restrict__ root_lo,
     const cs_val *__restrict__ states_in, const unsigned long long *__restrict__ forb_in,
     const cs_node_in *__restrict__ nodes, cs_val *__restrict__ states_out, unsigned long long *__restrict__ forb_out,
@@ -681,17 +681,65 @@ __global__ __launch_bounds__(1024, (FW <= 1 ? 8 : 4)) void cs_propagate_ne_bitse
     cs_node_out my_result;
     my_result.status = 0; my_result.props = 0; my_result.revisions = 0; my_result.rounds = 0;
 
+    /* software pipeline (R > 0): the state and the sets of node j+1 are in flight while node j
+     * is propagated */
+    constexpr int RP = R > 0 ? R : 1;
+    cs_val pre_dom[RP];
+    u64 pre_forb[RP * FW];
+    if (R > 0) {
+      const size_t prow0 = (size_t)__builtin_amdgcn_readlane(rec.parent, 0);
+#pragma unroll
+      for (int r = 0; r < RP; r++) {
+        const int v = lane + r * CS_WAVE;
+        pre_dom[r] = v < n ? states_in[prow0 * n + v] : cs_value(0);
+      }
+      if (forb_in != nullptr) {
+#pragma unroll
+        for (int r = 0; r < RP * FW; r++) {
+          const int k = lane + r * CS_WAVE;
+          pre_forb[r] = k < n * FW ? forb_in[prow0 * n * FW + k] : 0ull;
+        }
+      }
+    }
     for (int j = 0; j < cnt; j++) {
       const int nvar = __builtin_amdgcn_readlane(rec.var, j);
       const int nlo = __builtin_amdgcn_readlane(rec.lo, j), nhi = __builtin_amdgcn_readlane(rec.hi, j);
       const size_t prow = (size_t)__builtin_amdgcn_readlane(rec.parent, j);
-      const cs_val *src = states_in + prow * n;
-      for (int v = lane; v < n; v += CS_WAVE) dom[v] = src[v];
-      if (forb_in != nullptr) {
-        const u64 *fsrc = forb_in + prow * n * FW;
-        for (int k = lane; k < n * FW; k += CS_WAVE) forb[k] = fsrc[k];
+      if (R > 0) {
+#pragma unroll
+        for (int r = 0; r < RP; r++) {
+          const int v = lane + r * CS_WAVE;
+          if (v < n) dom[v] = pre_dom[r];
+        }
+#pragma unroll
+        for (int r = 0; r < RP * FW; r++) {
+          const int k = lane + r * CS_WAVE;
+          if (k < n * FW) forb[k] = forb_in != nullptr ? pre_forb[r] : 0ull;
+        }
+        if (j + 1 < cnt) {
+          const size_t pnext = (size_t)__builtin_amdgcn_readlane(rec.parent, j + 1);
+#pragma unroll
+          for (int r = 0; r < RP; r++) {
+            const int v = lane + r * CS_WAVE;
+            pre_dom[r] = v < n ? states_in[pnext * n + v] : cs_value(0);
+          }
+          if (forb_in != nullptr) {
+#pragma unroll
+            for (int r = 0; r < RP * FW; r++) {
+              const int k = lane + r * CS_WAVE;
+              pre_forb[r] = k < n * FW ? forb_in[pnext * n * FW + k] : 0ull;
+            }
+          }
+        }
       } else {
-        for (int k = lane; k < n * FW; k += CS_WAVE) forb[k] = 0ull;
+        const cs_val *src = states_in + prow * n;
+        for (int v = lane; v < n; v += CS_WAVE) dom[v] = src[v];
+        if (forb_in != nullptr) {
+          const u64 *fsrc = forb_in + prow * n * FW;
+          for (int k = lane; k < n * FW; k += CS_WAVE) forb[k] = fsrc[k];
+        } else {
+          for (int k = lane; k < n * FW; k += CS_WAVE) forb[k] = 0ull;
+        }
       }
       for (int w = lane; w < nw; w += CS_WAVE) { mask_a[w] = 0u; mask_b[w] = 0u; }
       cs_wave_sync();

@@ -191,7 +191,7 @@ def search_workload(args, rank, world, local, dist):
     Strong scaling: the tree is fixed, every step is one complete search."""
     from csolve_amd.parallel import ShardedSearch
     from csolve_amd.solver import Search
-    text = problems.queens(args.search_queens, "ALL")
+    text = problems.queens(args.search_queens, args.search_objective)
     model = solve_root(text)
     n = model.n_vars
     comm = "cpu" if args.comm == "gloo" else "cuda"
@@ -234,7 +234,7 @@ def search_workload(args, rank, world, local, dist):
             "nodes_per_s": totals["nodes"] * args.steps / elapsed, "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": f"queens-{args.search_queens} ALL, full search sharded GPU-per-subtree "
+            "config": {"workload": f"queens-{args.search_queens} {args.search_objective}, full search sharded GPU-per-subtree "
                                    f"(BASELINE configs[3] shape)", "solutions": totals["solutions"],
                        "nodes": totals["nodes"], "cuts": totals["cuts"], "props": totals["props"],
                        "iterations": totals["iterations"], "states_moved_between_ranks": int(moved.item()),
@@ -254,6 +254,7 @@ def main():
     ap.add_argument("--rebuild-sets", action="store_true", help="forbidden-set kernel without resident sets")
     ap.add_argument("--workload", choices=["propagate", "search"], default="propagate")
     ap.add_argument("--search-queens", type=int, default=13)
+    ap.add_argument("--search-objective", choices=["ALL", "ANY"], default="ALL")
     ap.add_argument("--pool", type=int, default=1 << 21)
     ap.add_argument("--children", type=int, default=1 << 17)
     ap.add_argument("--slice", type=int, default=32, help="search iterations between rank exchanges")

@@ -94,6 +94,7 @@ def load_library():
     L.csgpu_search_put.argtypes = [vp, vp, i64]
     L.csgpu_search_take.argtypes = [vp, vp, i64, C.POINTER(i64)]
     L.csgpu_search_set_best.argtypes = [vp, i32]
+    L.csgpu_search_set_parents.argtypes = [vp, i64]
     L.csgpu_search_run.argtypes = [vp, i64, C.POINTER(SearchStats)]
     L.csgpu_search_solutions.argtypes = [vp, vp, i64]
     L.csgpu_search_solutions.restype = i64

@@ -22,7 +22,7 @@ enum { C_SURVIVORS = 0, C_COMPLETE, C_CUTS, C_PROPS, C_REVS, C_SOLUTIONS, C_STOR
 struct csgpu_search {
   const csgpu_model *m;
   int n, objective, obj_var;
-  int64_t cap, max_children, max_parents, max_width;
+  int64_t cap, max_children, max_parents, max_width, parents_limit;
   cs_val *pool;
   int64_t top, peak;
   /* forbidden sets travelling with the states (pure binary-NE models, csgpu_propagate_batch_fb) */
@@ -314,6 +314,8 @@ extern "C" int csgpu_search_create(const csgpu_model *m, int64_t pool_capacity, 
   if (max_children > 0x3fffffff) return fail(CSGPU_E_LIMIT, "max_children too large");
   s->max_children = max_children;
   s->max_parents = max_children / s->max_width;
+  s->parents_limit = csgpu_model_objective(m) == CS_OBJ_ANY ? 64 : s->max_parents;
+  if (s->parents_limit > s->max_parents) s->parents_limit = s->max_parents;
   if (pool_capacity < max_children + 1) pool_capacity = max_children + 1;
   if (pool_capacity > 0x7fffffff) return fail(CSGPU_E_LIMIT, "pool_capacity too large");
   s->cap = pool_capacity;
@@ -400,6 +402,12 @@ extern "C" int csgpu_search_take(csgpu_search *s, csgpu_val *d_states, int64_t m
   return CSGPU_OK;
 }
 
+extern "C" int csgpu_search_set_parents(csgpu_search *s, int64_t parents_per_iteration) {
+  if (s == NULL || parents_per_iteration < 1) return fail(CSGPU_E_ARG, "bad argument");
+  s->parents_limit = parents_per_iteration < s->max_parents ? parents_per_iteration : s->max_parents;
+  return CSGPU_OK;
+}
+
 extern "C" int csgpu_search_set_best(csgpu_search *s, int32_t best) {
   if (s == NULL) return fail(CSGPU_E_ARG, "bad argument");
   int better = (s->objective == CS_OBJ_MIN && best < s->st.best) || (s->objective == CS_OBJ_MAX && best > s->st.best);
@@ -412,7 +420,7 @@ extern "C" int csgpu_search_set_best(csgpu_search *s, int32_t best) {
 
 static int one_iteration(csgpu_search *s) {
   const int n = s->n;
-  int64_t parents = s->top < s->max_parents ? s->top : s->max_parents;
+  int64_t parents = s->top < s->parents_limit ? s->top : s->parents_limit;
   /* survivors go back above the consumed parents: guaranteed room for max_children rows */
   if (s->top - parents + s->max_children > s->cap) {
     parents = s->top < 1 ? 0 : 1; /* a nearly full pool: fall back to strict depth-first */

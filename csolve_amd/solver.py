@@ -248,6 +248,9 @@ class Search:
         check(load_library().csgpu_search_take(self._h, buf.data_ptr(), max_states, C.byref(cnt)))
         return buf[: cnt.value]
 
+    def set_parents(self, parents_per_iteration: int):
+        check(load_library().csgpu_search_set_parents(self._h, int(parents_per_iteration)))
+
     def set_best(self, best: int):
         check(load_library().csgpu_search_set_best(self._h, int(best)))
 

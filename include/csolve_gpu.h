@@ -194,6 +194,10 @@ void csgpu_search_free(csgpu_search *s);
 int csgpu_search_put(csgpu_search *s, const csgpu_val *d_states, int64_t count);
 /* remove up to `max` of the OLDEST states (the largest subtrees) into d_states; *count = how many */
 int csgpu_search_take(csgpu_search *s, csgpu_val *d_states, int64_t max, int64_t *count);
+/* cap on the open states expanded per iteration (default: as many as max_children allows for
+ * ALL/MIN/MAX, 64 for ANY, which makes the walk depth-first enough to reach a first solution
+ * with a small pool) */
+int csgpu_search_set_parents(csgpu_search *s, int64_t parents_per_iteration);
 /* merge an incumbent found elsewhere (objective_best of the shared page, objective.c:89-93) */
 int csgpu_search_set_best(csgpu_search *s, int32_t best);
 /* run up to max_iterations iterations (stops early when done) */

@@ -36,12 +36,17 @@ def test_all_solutions_of_queens(n, count):
         assert len(set(row)) == n and len(set(row + np.arange(n))) == n and len(set(row - np.arange(n))) == n
 
 
-def test_any_stops_at_first_solution():
+@pytest.mark.parametrize("n", [16, 64, 128])
+def test_any_stops_at_first_solution(n):
+    """ANY: depth-first enough (64 open states expanded per iteration) to reach a first solution of
+    queens-64 and queens-128 (BASELINE configs[3] instance) with a small pool; the solution is valid."""
     from csolve_amd import problems
-    model, s, st = _solve(problems.queens(16))
+    model, s, st = _solve(problems.queens(n), pool=1 << 20, children=1 << 16, iters=5000)
     assert st["done"] == 1 and st["solutions"] >= 1
     row = s.solutions(1)[0]
-    assert len(set(row)) == 16 and len(set(row + np.arange(16))) == 16 and len(set(row - np.arange(16))) == 16
+    assert len(set(row)) == n and len(set(row + np.arange(n))) == n and len(set(row - np.arange(n))) == n
+    truth = model.eval_root(torch.from_numpy(np.stack([row, row], 1)[None].astype(np.int32)).cuda())
+    assert int(truth[0]) == 1
 
 
 @pytest.mark.parametrize("name,best", [("ref_schedule", 11), ("schedule6_s1", 22), ("ref_wcet", 1560)])

@@ -295,6 +295,14 @@ extern "C" int csgpu_model_root_propagate(csgpu_model *m, int32_t *status) {
   return rc;
 }
 
+extern "C" int csgpu_model_normalize(csgpu_model *m) {
+  if (m == NULL) return set_err(CSGPU_E_ARG, "null argument");
+  if (m->from_dump) return set_err(CSGPU_E_STATE, "a dumped model is already normalised");
+  if (m->finalized) return set_err(CSGPU_E_STATE, "model is already finalized");
+  if (cs_model_normalize(m->host) < 0) return set_err(CSGPU_E_STATE, "model has no root");
+  return CSGPU_OK;
+}
+
 extern "C" int csgpu_model_eval_clauses_host(csgpu_model *m, csgpu_val *vals) {
   if (m == NULL || vals == NULL) return set_err(CSGPU_E_ARG, "null argument");
   cs_model *h = m->host;

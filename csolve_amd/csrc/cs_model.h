@@ -83,6 +83,10 @@ cs_model *cs_model_parse(const char *text, int weights_on, char *err, size_t err
  * already a single value gets no clause list. */
 int cs_model_index(cs_model *m);
 
+/* the root normalisation pass (cs_normalize.c; reference src/normalize.c:305-316).  Rewrites the
+ * trees in place using the current domains, drops the clause index.  Returns the root node. */
+int32_t cs_model_normalize(cs_model *m);
+
 /* env_generate() check (parser_support.c:245-257): index of the first variable with
  * an infinite bound, or -1 */
 int32_t cs_model_first_unbounded(const cs_model *m);

@@ -314,7 +314,10 @@ extern "C" int csgpu_search_create(const csgpu_model *m, int64_t pool_capacity, 
   if (max_children > 0x3fffffff) return fail(CSGPU_E_LIMIT, "max_children too large");
   s->max_children = max_children;
   s->max_parents = max_children / s->max_width;
-  s->parents_limit = csgpu_model_objective(m) == CS_OBJ_ANY ? 64 : s->max_parents;
+  /* ALL walks the whole tree anyway: widest batches.  ANY/MIN/MAX profit from going deep first
+   * (a first solution / a good incumbent early prunes everything else), so only the newest 64
+   * open states are expanded per iteration. */
+  s->parents_limit = csgpu_model_objective(m) == CS_OBJ_ALL ? s->max_parents : 64;
   if (s->parents_limit > s->max_parents) s->parents_limit = s->max_parents;
   if (pool_capacity < max_children + 1) pool_capacity = max_children + 1;
   if (pool_capacity > 0x7fffffff) return fail(CSGPU_E_LIMIT, "pool_capacity too large");

@@ -117,6 +117,11 @@ class Model:
         check(load_library().csgpu_model_build_tables(self._h))
         return self
 
+    def normalize(self):
+        """normalize(root): host-side rewrite of the trees between the two root propagations"""
+        check(load_library().csgpu_model_normalize(self._h))
+        return self
+
     def finalize(self):
         check(load_library().csgpu_model_finalize(self._h))
         self.finalized = True
@@ -267,9 +272,12 @@ class Search:
 
 
 def solve_root(text: str, weights_on: bool = True) -> Model:
-    """Front end + root phase + finalize: parser.y's Input action up to clauses_init,
-    without the (cost-only) normalisation pass."""
+    """Front end + root phase + finalize: parser.y's Input action up to clauses_init
+    (propagate, normalize, propagate, env_generate, clauses_init)."""
     m = Model.from_text(text, weights_on)
+    if m.root_propagate() < 0:
+        raise ValueError("INFEASIBLE PROBLEM")
+    m.normalize()
     if m.root_propagate() < 0:
         raise ValueError("INFEASIBLE PROBLEM")
     return m.finalize()

@@ -99,6 +99,11 @@ int csgpu_model_device_info(const csgpu_model *m, int64_t info[8]);
  * which is the same state whenever the reference reaches its fixpoint within the limit.) */
 int csgpu_model_root_propagate(csgpu_model *m, int32_t *status);
 
+/* The root normalisation pass between the two root propagations (normalize(), reference
+ * src/normalize.c:305-316, parser.y:66): a host-side rewrite of the trees (constant folding,
+ * neutral elements, constants moved across `<`, double negation, De Morgan); no domain changes. */
+int csgpu_model_normalize(csgpu_model *m);
+
 /* eval_<op> on the current root domains, host buffers, no finalize needed (variables may
  * still be unbounded): vals[c] = interval value of clause c (eval.c:27-255).  Synchronous. */
 int csgpu_model_eval_clauses_host(csgpu_model *m, csgpu_val *vals);
@@ -195,8 +200,8 @@ int csgpu_search_put(csgpu_search *s, const csgpu_val *d_states, int64_t count);
 /* remove up to `max` of the OLDEST states (the largest subtrees) into d_states; *count = how many */
 int csgpu_search_take(csgpu_search *s, csgpu_val *d_states, int64_t max, int64_t *count);
 /* cap on the open states expanded per iteration (default: as many as max_children allows for
- * ALL/MIN/MAX, 64 for ANY, which makes the walk depth-first enough to reach a first solution
- * with a small pool) */
+ * ALL; 64 for ANY/MIN/MAX, which makes the walk depth-first enough to reach a first solution or a
+ * good incumbent early with a small pool) */
 int csgpu_search_set_parents(csgpu_search *s, int64_t parents_per_iteration);
 /* merge an incumbent found elsewhere (objective_best of the shared page, objective.c:89-93) */
 int csgpu_search_set_best(csgpu_search *s, int32_t best);

@@ -66,6 +66,8 @@ def lib():
         L.cs_model_load.argtypes = [C.c_char_p, C.c_char_p, sz]
         L.cs_model_save.argtypes = [vp, C.c_char_p]
         L.cs_model_index.argtypes = [vp]
+        L.cs_model_normalize.restype = i32
+        L.cs_model_normalize.argtypes = [vp]
         L.cs_model_add_var.restype = i32
         L.cs_model_add_var.argtypes = [vp, C.c_char_p, Val]
         L.cs_model_add_node.restype = i32
@@ -186,6 +188,11 @@ class Model:
     def index(self):
         if lib().cs_model_index(self.ptr) != 0:
             raise ValueError("cs_model_index failed")
+
+    def normalize(self):
+        """host normaliser of the product (csolve_amd/csrc/cs_normalize.c), for model-parity tests"""
+        if lib().cs_model_normalize(self.ptr) < 0:
+            raise ValueError("cs_model_normalize failed")
 
     def save(self, path: str):
         if lib().cs_model_save(self.ptr, path.encode()) != 0:

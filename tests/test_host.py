@@ -139,3 +139,25 @@ def test_generators_are_deterministic_and_reference_shaped():
     for br in range(5):
         for bc in range(5):
             assert sorted(grid[br * 5 + i][bc * 5 + j] for i in range(5) for j in range(5)) == list(range(1, 26))
+
+
+@pytest.mark.parametrize("name", MODELS)
+def test_front_end_plus_normaliser_reproduce_the_reference_trees(name):
+    """Input action replayed on the host side (root sweeps by the oracle here, by the device in the
+    product): parse, propagate, normalize, propagate, clauses_init.  The resulting model -- every
+    tree node for node, every per-variable clause list entry for entry, domains, weights -- equals
+    what the compiled reference dumped after its own root phase."""
+    ref = OModel.load(golden("models", name + ".model"))
+    mine = OModel.parse(open(golden("problems", name + ".txt")).read())
+    o = Oracle(mine)
+    o.set_root_phase(True)
+    assert o.propagate(mine.root, mine.n_vars) >= 0
+    mine.set_domains(o.domains())
+    mine.normalize()
+    o = Oracle(mine)
+    o.set_root_phase(True)
+    assert o.propagate(mine.root, mine.n_vars) >= 0
+    mine.set_domains(o.domains())
+    mine.index()
+    ok, why = mine.equal(ref)
+    assert ok, why

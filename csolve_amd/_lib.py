@@ -26,7 +26,7 @@ class Node(C.Structure):
 
 class SearchStats(C.Structure):
     _fields_ = [("nodes", C.c_uint64), ("cuts", C.c_uint64), ("props", C.c_uint64), ("revisions", C.c_uint64),
-                ("solutions", C.c_uint64), ("iterations", C.c_uint64), ("pool", C.c_int64), ("pool_peak", C.c_int64),
+                ("solutions", C.c_uint64), ("iterations", C.c_uint64), ("restarts", C.c_uint64), ("pool", C.c_int64), ("pool_peak", C.c_int64),
                 ("best", C.c_int32), ("done", C.c_int32)]
 
 
@@ -96,6 +96,7 @@ def load_library():
     L.csgpu_search_take.argtypes = [vp, vp, i64, C.POINTER(i64)]
     L.csgpu_search_set_best.argtypes = [vp, i32]
     L.csgpu_search_set_parents.argtypes = [vp, i64]
+    L.csgpu_search_set_restart.argtypes = [vp, i64]
     L.csgpu_search_run.argtypes = [vp, i64, C.POINTER(SearchStats)]
     L.csgpu_search_solutions.argtypes = [vp, vp, i64]
     L.csgpu_search_solutions.restype = i64

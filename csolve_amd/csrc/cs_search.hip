@@ -34,11 +34,16 @@ struct csgpu_search {
   cs_val *d_child_states, *d_complete_states;
   csgpu_result *d_results;
   int *d_dest, *d_complete_list, *d_truth;
+  int *d_block_surv, *d_block_comp, *d_surv_off, *d_comp_off;
   unsigned long long *d_counters; /* [C_COUNT] */
   int *d_best;
   int32_t *d_solutions;           /* [max_solutions][n] */
   int64_t max_solutions;
   csgpu_search_stats st;
+  /* restarts (ANY): the states put from outside are kept to restart from */
+  cs_val *seed;
+  int64_t seed_count, seed_cap, restart_base, since_restart;
+  uint64_t luby_threshold, luby_counter;
 };
 
 extern "C" int csgpu_internal_set_error(int code, const char *msg); /* cs_capi.hip */
@@ -88,7 +93,7 @@ __global__ __launch_bounds__(SB) void cs_branch(const cs_val *__restrict__ pool,
 
 /* exclusive scan of child_count[0..parents) by one block; total -> counters[C_TOTAL_CHILDREN] */
 __global__ __launch_bounds__(1024) void cs_scan(const int *__restrict__ count, int parents, int *__restrict__ off,
-                                                unsigned long long *__restrict__ counters) {
+                                                unsigned long long *__restrict__ counters, int total_slot) {
   __shared__ long long part[1024];
   const int t = threadIdx.x;
   const int per = (parents + 1023) / 1024;
@@ -110,14 +115,15 @@ __global__ __launch_bounds__(1024) void cs_scan(const int *__restrict__ count, i
   }
   if (t == 1023) {
     off[parents] = (int)part[1023];
-    counters[C_TOTAL_CHILDREN] = (unsigned long long)part[1023];
+    counters[total_slot] = (unsigned long long)part[1023];
   }
 }
 
 /* one wave per parent writes its children {var, value, value, parent_row} */
 __global__ __launch_bounds__(SB) void cs_emit(const cs_val *__restrict__ pool, long long first_row, int parents, int n,
                                               const int *__restrict__ branch_var, const int *__restrict__ child_off,
-                                              csgpu_node *__restrict__ nodes, int low_values_last) {
+                                              csgpu_node *__restrict__ nodes, int low_values_last,
+                                              unsigned scramble) {
   const int lane = threadIdx.x & 63;
   const int p = blockIdx.x * (SB / 64) + (threadIdx.x >> 6);
   if (p >= parents) return;
@@ -142,7 +148,15 @@ __global__ __launch_bounds__(SB) void cs_emit(const cs_val *__restrict__ pool, l
   }
   for (int k = lane; k < cnt; k += 64) {
     csgpu_node nd;
-    const int value = low_values_last ? d.hi - k : d.lo + k;
+    int value = low_values_last ? d.hi - k : d.lo + k;
+    if (scramble != 0u) {
+      /* ANY: the values are tried from a pseudo-random starting point (the reference randomises its
+       * value order too: the seed of step_val, csolve.c:284,331-338).  Deterministic: a function of
+       * the variable, the row and the iteration only. */
+      unsigned h = (scramble ^ (unsigned)var * 2654435761u ^ (unsigned)(first_row + p) * 40503u);
+      h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+      value = d.lo + (int)(((unsigned)k + h) % (unsigned)cnt);
+    }
     nd.var = var;
     nd.lo = value;
     nd.hi = value;
@@ -151,13 +165,13 @@ __global__ __launch_bounds__(SB) void cs_emit(const cs_val *__restrict__ pool, l
   }
 }
 
-/* classify the children: survivors get a pool row, complete ones go to the solution check */
-__global__ __launch_bounds__(SB) void cs_select(const csgpu_result *__restrict__ res, int children, long long new_top,
-                                                int *__restrict__ dest, int *__restrict__ complete_list,
-                                                unsigned long long *__restrict__ counters) {
-  __shared__ int s_surv[SB], s_comp[SB];
-  __shared__ unsigned long long s_base[2];
-  __shared__ unsigned long long s_sum[3];
+/* Classification of the children, deterministic: pool rows and the order of the solution check
+ * depend on the child index only (block counts -> exclusive scan -> rows), never on which
+ * workgroup finished first, so a search is reproducible run to run. */
+__global__ __launch_bounds__(SB) void cs_classify_count(const csgpu_result *__restrict__ res, int children,
+                                                        int *__restrict__ block_surv, int *__restrict__ block_comp,
+                                                        unsigned long long *__restrict__ counters) {
+  __shared__ unsigned long long s_sum[5];
   const int t = threadIdx.x, i = blockIdx.x * SB + t;
   int status = -2, props = 0, revs = 0;
   if (i < children) {
@@ -165,10 +179,44 @@ __global__ __launch_bounds__(SB) void cs_select(const csgpu_result *__restrict__
     props = res[i].props;
     revs = res[i].revisions;
   }
-  const int surv = status > 0, comp = status == 0, cut = status == -1;
+  if (t < 5) s_sum[t] = 0ull;
+  __syncthreads();
+  unsigned long long ps = status > 0, pk = status == 0, pc = status == -1, pp = (unsigned long long)props,
+                     pr = (unsigned long long)revs;
+  for (int o = 32; o > 0; o >>= 1) {
+    ps += __shfl_xor(ps, o);
+    pk += __shfl_xor(pk, o);
+    pc += __shfl_xor(pc, o);
+    pp += __shfl_xor(pp, o);
+    pr += __shfl_xor(pr, o);
+  }
+  if ((t & 63) == 0) {
+    atomicAdd(&s_sum[0], ps);
+    atomicAdd(&s_sum[1], pk);
+    atomicAdd(&s_sum[2], pc);
+    atomicAdd(&s_sum[3], pp);
+    atomicAdd(&s_sum[4], pr);
+  }
+  __syncthreads();
+  if (t == 0) {
+    block_surv[blockIdx.x] = (int)s_sum[0];
+    block_comp[blockIdx.x] = (int)s_sum[1];
+    atomicAdd(&counters[C_CUTS], s_sum[2]); /* sums do not depend on the order */
+    atomicAdd(&counters[C_PROPS], s_sum[3]);
+    atomicAdd(&counters[C_REVS], s_sum[4]);
+  }
+}
+
+__global__ __launch_bounds__(SB) void cs_classify_assign(const csgpu_result *__restrict__ res, int children,
+                                                         long long new_top, const int *__restrict__ surv_off,
+                                                         const int *__restrict__ comp_off, int *__restrict__ dest,
+                                                         int *__restrict__ complete_list) {
+  __shared__ int s_surv[SB], s_comp[SB];
+  const int t = threadIdx.x, i = blockIdx.x * SB + t;
+  const int status = i < children ? res[i].status : -2;
+  const int surv = status > 0, comp = status == 0;
   s_surv[t] = surv;
   s_comp[t] = comp;
-  if (t < 3) s_sum[t] = 0ull;
   __syncthreads();
   for (int d = 1; d < SB; d <<= 1) {
     int a = t >= d ? s_surv[t - d] : 0, b = t >= d ? s_comp[t - d] : 0;
@@ -177,30 +225,9 @@ __global__ __launch_bounds__(SB) void cs_select(const csgpu_result *__restrict__
     s_comp[t] += b;
     __syncthreads();
   }
-  /* wave-level partial sums of the statistics, then one atomic per block */
-  unsigned long long pc = (unsigned long long)cut, pp = (unsigned long long)props, pr = (unsigned long long)revs;
-  for (int o = 32; o > 0; o >>= 1) {
-    pc += __shfl_xor(pc, o);
-    pp += __shfl_xor(pp, o);
-    pr += __shfl_xor(pr, o);
-  }
-  if ((t & 63) == 0) {
-    atomicAdd(&s_sum[0], pc);
-    atomicAdd(&s_sum[1], pp);
-    atomicAdd(&s_sum[2], pr);
-  }
-  __syncthreads();
-  if (t == 0) {
-    s_base[0] = atomicAdd(&counters[C_SURVIVORS], (unsigned long long)s_surv[SB - 1]);
-    s_base[1] = atomicAdd(&counters[C_COMPLETE], (unsigned long long)s_comp[SB - 1]);
-    atomicAdd(&counters[C_CUTS], s_sum[0]);
-    atomicAdd(&counters[C_PROPS], s_sum[1]);
-    atomicAdd(&counters[C_REVS], s_sum[2]);
-  }
-  __syncthreads();
   if (i < children) {
-    dest[i] = surv ? (int)(new_top + (long long)s_base[0] + s_surv[t] - 1) : -1;
-    if (comp) complete_list[s_base[1] + s_comp[t] - 1] = i;
+    dest[i] = surv ? (int)(new_top + surv_off[blockIdx.x] + s_surv[t] - 1) : -1;
+    if (comp) complete_list[comp_off[blockIdx.x] + s_comp[t] - 1] = i;
   }
 }
 
@@ -259,7 +286,7 @@ __global__ __launch_bounds__(SB) void cs_accept(const cs_val *__restrict__ compl
     atomicAdd(&counters[C_SOLUTIONS], 1ull);
     if (objective == CS_OBJ_MIN) atomicMin(best, row[obj_var].lo);
     if (objective == CS_OBJ_MAX) atomicMax(best, row[obj_var].hi);
-    slot = (long long)atomicAdd(&counters[C_STORED], 1ull);
+    slot = (long long)atomicAdd(&counters[C_STORED], 1ull); /* which solutions are kept may vary; their count does not */
   }
   slot = __shfl(slot, 0);
   if (slot < max_solutions)
@@ -283,7 +310,9 @@ extern "C" void csgpu_search_free(csgpu_search *s) {
   (void)hipFree(s->pool); (void)hipFree(s->d_branch_var); (void)hipFree(s->d_child_count); (void)hipFree(s->d_child_off);
   (void)hipFree(s->d_nodes); (void)hipFree(s->d_child_states); (void)hipFree(s->d_complete_states);
   (void)hipFree(s->d_results); (void)hipFree(s->d_dest); (void)hipFree(s->d_complete_list); (void)hipFree(s->d_truth);
+  (void)hipFree(s->d_block_surv); (void)hipFree(s->d_block_comp); (void)hipFree(s->d_surv_off); (void)hipFree(s->d_comp_off);
   (void)hipFree(s->d_counters); (void)hipFree(s->d_best); (void)hipFree(s->d_solutions);
+  (void)hipFree(s->seed);
   free(s);
 }
 
@@ -323,6 +352,9 @@ extern "C" int csgpu_search_create(const csgpu_model *m, int64_t pool_capacity, 
   if (pool_capacity > 0x7fffffff) return fail(CSGPU_E_LIMIT, "pool_capacity too large");
   s->cap = pool_capacity;
   s->max_solutions = 1024;
+  s->restart_base = s->objective == CS_OBJ_ANY ? 64 : 0;
+  s->luby_threshold = 1;
+  s->luby_counter = 1;
   s->st.best = s->objective == CS_OBJ_MIN ? CS_DOM_MAX : (s->objective == CS_OBJ_MAX ? CS_DOM_MIN : 0);
   const size_t row = (size_t)n * sizeof(cs_val);
   hipError_t e;
@@ -348,6 +380,13 @@ extern "C" int csgpu_search_create(const csgpu_model *m, int64_t pool_capacity, 
   ALLOC(s->d_dest, sizeof(int) * (size_t)max_children);
   ALLOC(s->d_complete_list, sizeof(int) * (size_t)max_children);
   ALLOC(s->d_truth, sizeof(int) * (size_t)max_children);
+  {
+    const size_t blocks = ((size_t)max_children + SB - 1) / SB + 1;
+    ALLOC(s->d_block_surv, sizeof(int) * blocks);
+    ALLOC(s->d_block_comp, sizeof(int) * blocks);
+    ALLOC(s->d_surv_off, sizeof(int) * (blocks + 1));
+    ALLOC(s->d_comp_off, sizeof(int) * (blocks + 1));
+  }
   ALLOC(s->d_counters, sizeof(unsigned long long) * C_COUNT);
   ALLOC(s->d_best, sizeof(int));
   ALLOC(s->d_solutions, sizeof(int32_t) * (size_t)n * (size_t)s->max_solutions);
@@ -379,8 +418,30 @@ extern "C" int csgpu_search_put(csgpu_search *s, const csgpu_val *d_states, int6
                        (size_t)k * s->n * s->fw * 8, hipMemcpyDeviceToDevice));
     }
   }
+  if (count > 0 && s->restart_base > 0 && !s->st.iterations) {
+    /* remember what the search was started from (only states put before the first iteration) */
+    if (s->seed_count + count > s->seed_cap) {
+      const int64_t cap = (s->seed_count + count) * 2;
+      cs_val *grown = NULL;
+      HIP_OK(hipMalloc((void **)&grown, (size_t)cap * s->n * sizeof(cs_val)));
+      if (s->seed_count > 0)
+        HIP_OK(hipMemcpy(grown, s->seed, (size_t)s->seed_count * s->n * sizeof(cs_val), hipMemcpyDeviceToDevice));
+      (void)hipFree(s->seed);
+      s->seed = grown;
+      s->seed_cap = cap;
+    }
+    HIP_OK(hipMemcpy(s->seed + (size_t)s->seed_count * s->n, d_states, (size_t)count * s->n * sizeof(cs_val),
+                     hipMemcpyDeviceToDevice));
+    s->seed_count += count;
+  }
   s->top += count;
   if (s->top > s->peak) s->peak = s->top;
+  return CSGPU_OK;
+}
+
+extern "C" int csgpu_search_set_restart(csgpu_search *s, int64_t iterations) {
+  if (s == NULL || iterations < 0) return fail(CSGPU_E_ARG, "bad argument");
+  s->restart_base = s->objective == CS_OBJ_ANY ? iterations : 0;
   return CSGPU_OK;
 }
 
@@ -435,13 +496,15 @@ static int one_iteration(csgpu_search *s) {
   const unsigned pb = (unsigned)((parents + 3) / 4);
   hipLaunchKernelGGL(cs_branch, dim3(pb), dim3(SB), 0, 0, s->pool, first_row, (int)parents, n, s->d_branch_var,
                      s->d_child_count);
-  hipLaunchKernelGGL(cs_scan, dim3(1), dim3(1024), 0, 0, s->d_child_count, (int)parents, s->d_child_off, s->d_counters);
+  hipLaunchKernelGGL(cs_scan, dim3(1), dim3(1024), 0, 0, s->d_child_count, (int)parents, s->d_child_off, s->d_counters,
+                     (int)C_TOTAL_CHILDREN);
   unsigned long long total = 0;
   HIP_OK(hipMemcpy(&total, s->d_counters + C_TOTAL_CHILDREN, sizeof total, hipMemcpyDeviceToHost));
   const int64_t children = (int64_t)total;
   if (children > s->max_children) return fail(CSGPU_E_LIMIT, "internal: more children than the batch buffers hold");
   hipLaunchKernelGGL(cs_emit, dim3(pb), dim3(SB), 0, 0, s->pool, first_row, (int)parents, n, s->d_branch_var,
-                     s->d_child_off, s->d_nodes, s->objective == CS_OBJ_MAX ? 0 : 1);
+                     s->d_child_off, s->d_nodes, s->objective == CS_OBJ_MAX ? 0 : 1,
+                     s->objective == CS_OBJ_ANY ? (unsigned)(s->st.iterations * 2654435761ull + 0x9e3779b9u) | 1u : 0u);
   s->top -= parents;
   s->st.iterations++;
   if (children == 0) return CSGPU_OK;
@@ -460,8 +523,14 @@ static int one_iteration(csgpu_search *s) {
                                    s->d_results, children, obj_lo, obj_hi, NULL);
   if (rc != CSGPU_OK) return rc;
   const unsigned cb = (unsigned)((children + SB - 1) / SB), cw = (unsigned)((children + 3) / 4);
-  hipLaunchKernelGGL(cs_select, dim3(cb), dim3(SB), 0, 0, s->d_results, (int)children, (long long)s->top, s->d_dest,
-                     s->d_complete_list, s->d_counters);
+  hipLaunchKernelGGL(cs_classify_count, dim3(cb), dim3(SB), 0, 0, s->d_results, (int)children, s->d_block_surv,
+                     s->d_block_comp, s->d_counters);
+  hipLaunchKernelGGL(cs_scan, dim3(1), dim3(1024), 0, 0, s->d_block_surv, (int)cb, s->d_surv_off, s->d_counters,
+                     (int)C_SURVIVORS);
+  hipLaunchKernelGGL(cs_scan, dim3(1), dim3(1024), 0, 0, s->d_block_comp, (int)cb, s->d_comp_off, s->d_counters,
+                     (int)C_COMPLETE);
+  hipLaunchKernelGGL(cs_classify_assign, dim3(cb), dim3(SB), 0, 0, s->d_results, (int)children, (long long)s->top,
+                     s->d_surv_off, s->d_comp_off, s->d_dest, s->d_complete_list);
   hipLaunchKernelGGL(cs_scatter, dim3(cw), dim3(SB), 0, 0, s->d_child_states, s->d_dest, (int)children, n, s->pool,
                      s->d_child_forb, s->pool_forb, s->fw);
   unsigned long long c[C_COUNT];
@@ -501,6 +570,24 @@ extern "C" int csgpu_search_run(csgpu_search *s, int64_t max_iterations, csgpu_s
     if (s->objective == CS_OBJ_ANY && s->st.solutions > 0) break;
     int rc = one_iteration(s);
     if (rc != CSGPU_OK) return rc;
+    /* check_restart (csolve.c:264-276) with Knuth's Luby sequence (csolve.c:76-83) */
+    if (s->restart_base > 0 && s->seed_count > 0 && s->st.solutions == 0 &&
+        ++s->since_restart > (int64_t)s->luby_threshold * s->restart_base) {
+      s->since_restart = 0;
+      if ((s->luby_counter & (0 - s->luby_counter)) == s->luby_threshold) {
+        s->luby_counter++;
+        s->luby_threshold = 1;
+      } else {
+        s->luby_threshold <<= 1;
+      }
+      s->st.restarts++;
+      s->top = 0;
+      const int64_t keep = s->restart_base; /* do not record the re-seeding as new seeds */
+      s->restart_base = 0;
+      rc = csgpu_search_put(s, (const csgpu_val *)s->seed, s->seed_count);
+      s->restart_base = keep;
+      if (rc != CSGPU_OK) return rc;
+    }
   }
   s->st.pool = s->top;
   s->st.pool_peak = s->peak;

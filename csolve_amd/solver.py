@@ -256,6 +256,9 @@ class Search:
     def set_parents(self, parents_per_iteration: int):
         check(load_library().csgpu_search_set_parents(self._h, int(parents_per_iteration)))
 
+    def set_restart(self, iterations: int):
+        check(load_library().csgpu_search_set_restart(self._h, int(iterations)))
+
     def set_best(self, best: int):
         check(load_library().csgpu_search_set_best(self._h, int(best)))
 

@@ -186,6 +186,7 @@ typedef struct csgpu_search_stats {
   uint64_t revisions;  /* clause revisions */
   uint64_t solutions;  /* accepted solutions (root evaluates to true) */
   uint64_t iterations; /* batched expand+propagate rounds */
+  uint64_t restarts;   /* ANY only: Luby restarts (check_restart, csolve.c:264-276) */
   int64_t pool;        /* open states now in the pool */
   int64_t pool_peak;
   int32_t best;        /* incumbent (MIN/MAX), INT32_MAX / INT32_MIN if none yet */
@@ -203,6 +204,11 @@ int csgpu_search_take(csgpu_search *s, csgpu_val *d_states, int64_t max, int64_t
  * ALL; 64 for ANY/MIN/MAX, which makes the walk depth-first enough to reach a first solution or a
  * good incumbent early with a small pool) */
 int csgpu_search_set_parents(csgpu_search *s, int64_t parents_per_iteration);
+/* ANY only: restart from the seeded states after luby(i) x `iterations` iterations without a
+ * solution (the reference restarts after luby(i) x restart_frequency failures, csolve.c:76-83,
+ * 264-276, default 100); every restart tries the values in a different pseudo-random rotation.
+ * Default 64; 0 disables restarts. */
+int csgpu_search_set_restart(csgpu_search *s, int64_t iterations);
 /* merge an incumbent found elsewhere (objective_best of the shared page, objective.c:89-93) */
 int csgpu_search_set_best(csgpu_search *s, int32_t best);
 /* run up to max_iterations iterations (stops early when done) */

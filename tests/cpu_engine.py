@@ -19,7 +19,7 @@ class OracleEngine:
         self.obj_var = omodel.view.obj_var
         self.pool = []
         self.parents = parents_per_iteration
-        self.st = dict(nodes=0, cuts=0, props=0, revisions=0, solutions=0, iterations=0, pool=0, pool_peak=0,
+        self.st = dict(nodes=0, cuts=0, props=0, revisions=0, solutions=0, iterations=0, restarts=0, pool=0, pool_peak=0,
                        best=INT32_MAX if self.objective == OBJ_MIN else (INT32_MIN if self.objective == OBJ_MAX else 0),
                        done=0)
         self.found = []

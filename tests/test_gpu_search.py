@@ -105,3 +105,12 @@ def test_take_and_put_move_subtrees_between_engines():
     sa, sb = a.run(), b.run()
     assert sa["done"] and sb["done"]
     assert sa["solutions"] + sb["solutions"] == 352
+
+
+def test_search_is_reproducible():
+    """Two runs of the same search expand the same nodes in the same order (pool rows are assigned
+    from child indices, not from the order in which workgroups finish)."""
+    from csolve_amd import problems
+    runs = [_solve(problems.queens(40), pool=1 << 20, children=1 << 16, iters=400)[2] for _ in range(3)]
+    assert runs[0]["solutions"] >= 1
+    assert all(r == runs[0] for r in runs)

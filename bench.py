@@ -341,11 +341,15 @@ def main():
 
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     props_r, revs_r = int(res_h[:, 1].sum()), int(res_h[:, 2].sum())
-    # 32 B per clause revision + 8 B per narrowing + 16 B * n per node instance
-    alg_bytes = 32 * revs_r + 8 * props_r + 16 * n * B
+    # Algorithmic bytes of one launch = what the kernel's data layout obliges it to move over HBM
+    # (DESIGN.md 2/4): per node instance the state in and out (16 B x n), the forbidden sets in and
+    # out when they are resident (16 B x n x FW), the 16-B node record and the 16-B result.
+    # The clause tables are read once per workgroup from L2 and are not counted.
+    alg_bytes = (16 * n + (16 * n * fw if use_sets else 0) + 16 + 16) * B
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-    # what must cross HBM per node: state in + out (+ forbidden sets in + out), node record, result
-    stream_bytes = (16 * n + (16 * n * fw if use_sets else 0) + 16 + 16) * B
+    # SURVEY 8(d) also prices every clause revision as 32 B of memory traffic (+ 8 B per narrowing);
+    # in this design those bytes are LDS traffic, so that figure is reported separately
+    survey_bytes = 32 * revs_r + 8 * props_r + 16 * n * B
     out = {
         "metric": "constraint propagations/sec + nodes/sec, queens-N, 1/2/4/8 MI355X",
         "value": props_all * args.steps / elapsed,
@@ -370,8 +374,8 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(kernel_name, n_q, B),
                      "kernel": kernel_name, "kernel_ms": kernel_ms,
                      "algorithmic_bytes_per_launch": alg_bytes,
-                     "hbm_stream_bytes_per_launch": stream_bytes,
-                     "hbm_stream_frac": stream_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                     "bytes_per_node_instance": alg_bytes // B,
+                     "survey_8d_formula_gbps": survey_bytes / (kernel_ms * 1e-3) / 1e9},
     }
 
     if rank == 0 and world == 1 and not args.no_cpu:

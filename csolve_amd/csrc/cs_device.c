@@ -230,16 +230,23 @@ cs_dev_image *cs_dev_image_build(const cs_model *m, int with_lists, const unsign
     /* symmetric lists straight from the clause records */
     const int32_t n = m->n_vars;
     int32_t *cnt = (int32_t *)calloc((size_t)n + 1, sizeof(int32_t));
-    int32_t dmin = 0, dmax = 0;
+    /* the stored offset already contains the neighbour's root lower bound: an entry (w, dd) of u
+     * says "when u is the value c, bit c - dd of w's forbidden set is set" (dd = d + root_lo[w]) */
+    int64_t dmin64 = 0, dmax64 = 0;
+    int first = 1;
     for (int32_t c = 0; c < g->n_clauses; c++) {
       const int32_t *rec = &g->clause[4 * c];
       if (rec[0] != CS_CL_NE) continue;
       cnt[rec[1] + 1]++;
       cnt[rec[2] + 1]++;
-      const int32_t d = rec[3] < 0 ? -rec[3] : rec[3];
-      if (d > dmax) dmax = d;
+      const int64_t da = (int64_t)rec[3] + m->dom[rec[2]].lo, db = (int64_t)-rec[3] + m->dom[rec[1]].lo;
+      if (first) { dmin64 = dmax64 = da; first = 0; }
+      if (da < dmin64) dmin64 = da;
+      if (db < dmin64) dmin64 = db;
+      if (da > dmax64) dmax64 = da;
+      if (db > dmax64) dmax64 = db;
     }
-    dmin = -dmax;
+    const int32_t dmin = (int32_t)dmin64, dmax = (int32_t)dmax64;
     for (int32_t v = 0; v < n; v++) cnt[v + 1] += cnt[v];
     int obits = 1, dbits = 1;
     while ((1 << obits) < n) obits++;
@@ -259,8 +266,8 @@ cs_dev_image *cs_dev_image_build(const cs_model *m, int with_lists, const unsign
         const int32_t *rec = &g->clause[4 * c];
         if (rec[0] != CS_CL_NE) continue;
         /* X_a != X_b + d: seen from a -> (b, d); seen from b -> (a, -d) */
-        const uint32_t ea = (uint32_t)rec[2] | ((uint32_t)(rec[3] - dmin) << obits);
-        const uint32_t eb = (uint32_t)rec[1] | ((uint32_t)(-rec[3] - dmin) << obits);
+        const uint32_t ea = (uint32_t)rec[2] | ((uint32_t)(rec[3] + m->dom[rec[2]].lo - dmin) << obits);
+        const uint32_t eb = (uint32_t)rec[1] | ((uint32_t)(-rec[3] + m->dom[rec[1]].lo - dmin) << obits);
         const int32_t ia = fill[rec[1]]++, ib = fill[rec[2]]++;
         if (width == 2) { ((uint16_t *)g->sym_packed)[ia] = (uint16_t)ea; ((uint16_t *)g->sym_packed)[ib] = (uint16_t)eb; }
         else { ((uint32_t *)g->sym_packed)[ia] = ea; ((uint32_t *)g->sym_packed)[ib] = eb; }

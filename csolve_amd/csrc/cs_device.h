@@ -67,7 +67,8 @@ typedef struct cs_dev_image {
   /* symmetric adjacency for the forbidden-set kernel: every binary clause is listed under BOTH of
    * its variables, also under one that was already a single value at the root (the reference gives
    * such a variable no clause list, parser_support.c:341, because it can never change -- but its
-   * value must still reach the neighbours' forbidden sets) */
+   * value must still reach the neighbours' forbidden sets).  The packed offset of an entry (w, .)
+   * is d + root_lo[w], so that the bit index is simply value - offset. */
   int32_t sym_n_adj, sym_width, sym_obits, sym_dmin;
   int32_t *sym_off;     /* [n_vars+1] */
   void *sym_packed;     /* [sym_n_adj] */

@@ -661,6 +661,7 @@ __global__ __launch_bounds__(1024, (FW <= 1 && R <= 1 ? 8 : 4)) void cs_propagat
   u64 *forb = (u64 *)(dom + n);
   unsigned *mask_a = (unsigned *)(forb + (size_t)n * FW);
   unsigned *mask_b = mask_a + nw;
+  unsigned *pcount = mask_b + nw; /* propagations of the current node */
 
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     s_off2[i] = make_int2(T.adj_off[i], T.adj_off[i + 1]);
@@ -742,6 +743,7 @@ __global__ __launch_bounds__(1024, (FW <= 1 && R <= 1 ? 8 : 4)) void cs_propagat
         }
       }
       for (int w = lane; w < nw; w += CS_WAVE) { mask_a[w] = 0u; mask_b[w] = 0u; }
+      if (lane == 0) *pcount = 0u;
       cs_wave_sync();
       /* the assignment (step_enter, csolve.c:294-304) and the first set of variables to push */
       if (lane == 0 && nvar >= 0) dom[nvar] = cs_interval(nlo, nhi);
@@ -763,7 +765,7 @@ __global__ __launch_bounds__(1024, (FW <= 1 && R <= 1 ? 8 : 4)) void cs_propagat
       cs_wave_sync();
 
       unsigned *cur = mask_a, *nxt = mask_b;
-      int rounds = 0, failed = 0, revisions = 0, props = 0;
+      int rounds = 0, failed = 0, revisions = 0;
       for (;;) {
         /* (1) newly valued variables push their forbidden value into the neighbours' sets */
         for (int w = 0; w < nw; w++) {
@@ -778,7 +780,7 @@ __global__ __launch_bounds__(1024, (FW <= 1 && R <= 1 ? 8 : 4)) void cs_propagat
             for (int i = beg + lane; i < end; i += CS_WAVE) {
               const unsigned e = s_adj[i];
               const int wv = (int)(e & omask);
-              const int bit = c - ((int)(e >> obits) + dmin) - s_base[wv];
+              const int bit = c - ((int)(e >> obits) + dmin); /* the offset includes root_lo[wv] */
               if ((unsigned)bit < (unsigned)(64 * FW)) atomicOr(&forb[wv * FW + (bit >> 6)], 1ull << (bit & 63));
             }
           }
@@ -817,7 +819,7 @@ __global__ __launch_bounds__(1024, (FW <= 1 && R <= 1 ? 8 : 4)) void cs_propagat
               if (nlo2 > nhi2) {
                 fail = 1;
               } else if (nlo2 != lo || nhi2 != hi) {
-                props += (nlo2 - lo) + (hi - nhi2);
+                atomicAdd(pcount, (unsigned)((nlo2 - lo) + (hi - nhi2))); /* rare: a few lanes per node */
                 dom[v] = cs_interval(nlo2, nhi2);
                 newly = nlo2 == nhi2;
               }
@@ -839,7 +841,7 @@ __global__ __launch_bounds__(1024, (FW <= 1 && R <= 1 ? 8 : 4)) void cs_propagat
       }
       cs_wave_sync();
 
-      for (int off = 32; off > 0; off >>= 1) props += __shfl_xor(props, off);
+      const int props = (int)*pcount;
       int open_vars = 0;
       if (!failed) {
         cs_val *dst = states_out + (size_t)(base + j) * n;

@@ -742,25 +742,30 @@ __global__ __launch_bounds__(1024, (FW <= 1 && R <= 1 ? 8 : 4)) void cs_propagat
           for (int k = lane; k < n * FW; k += CS_WAVE) forb[k] = 0ull;
         }
       }
-      for (int w = lane; w < nw; w += CS_WAVE) { mask_a[w] = 0u; mask_b[w] = 0u; }
+      if (n > CS_WAVE)
+        for (int w = lane; w < nw; w += CS_WAVE) { mask_a[w] = 0u; mask_b[w] = 0u; }
       if (lane == 0) *pcount = 0u;
       cs_wave_sync();
       /* the assignment (step_enter, csolve.c:294-304) and the first set of variables to push */
       if (lane == 0 && nvar >= 0) dom[nvar] = cs_interval(nlo, nhi);
       cs_wave_sync();
+      const bool small = n <= CS_WAVE; /* one lane per variable: the push set lives in a scalar */
+      u64 cur64 = 0ull;
       if (forb_in == nullptr || nvar < 0) {
         /* no inherited sets: every valued variable of the incoming state pushes */
         for (int base_v = 0; base_v < n; base_v += CS_WAVE) {
           const int v = base_v + lane;
           const cs_val d = v < n ? dom[v] : cs_interval(0, 1);
           const u64 b = __ballot(d.lo == d.hi);
-          if (lane == 0) {
+          cur64 = b;
+          if (!small && lane == 0) {
             mask_a[base_v >> 5] = (unsigned)b;
             if ((base_v >> 5) + 1 < nw) mask_a[(base_v >> 5) + 1] = (unsigned)(b >> 32);
           }
         }
-      } else if (lane == 0 && nlo == nhi) {
-        mask_a[nvar >> 5] = 1u << (nvar & 31);
+      } else if (nlo == nhi) {
+        cur64 = 1ull << (nvar & 63);
+        if (!small && lane == 0) mask_a[nvar >> 5] = 1u << (nvar & 31);
       }
       cs_wave_sync();
 
@@ -768,11 +773,14 @@ __global__ __launch_bounds__(1024, (FW <= 1 && R <= 1 ? 8 : 4)) void cs_propagat
       int rounds = 0, failed = 0, revisions = 0;
       for (;;) {
         /* (1) newly valued variables push their forbidden value into the neighbours' sets */
-        for (int w = 0; w < nw; w++) {
-          unsigned bits = __builtin_amdgcn_readfirstlane(cur[w]);
-          while (bits != 0u) {
-            const int u = w * 32 + __builtin_ctz(bits);
-            bits &= bits - 1u;
+        const int words = small ? 1 : (nw + 1) / 2;
+        for (int w = 0; w < words; w++) {
+          u64 bits = small ? cur64
+                           : ((u64)(unsigned)__builtin_amdgcn_readfirstlane(cur[2 * w]) |
+                              ((u64)(2 * w + 1 < nw ? (unsigned)__builtin_amdgcn_readfirstlane(cur[2 * w + 1]) : 0u) << 32));
+          while (bits != 0ull) {
+            const int u = w * 64 + __builtin_ctzll(bits);
+            bits &= bits - 1ull;
             const int c = __builtin_amdgcn_readfirstlane(dom[u].lo);
             const int2 range = s_off2[u];
             const int beg = __builtin_amdgcn_readfirstlane(range.x), end = __builtin_amdgcn_readfirstlane(range.y);
@@ -786,9 +794,11 @@ __global__ __launch_bounds__(1024, (FW <= 1 && R <= 1 ? 8 : 4)) void cs_propagat
           }
         }
         cs_wave_sync();
-        for (int w = lane; w < nw; w += CS_WAVE) cur[w] = 0u;
+        if (!small)
+          for (int w = lane; w < nw; w += CS_WAVE) cur[w] = 0u;
         /* (2) every variable re-derives its bounds from its set */
         int fail = 0;
+        u64 any_new = 0ull;
         for (int base_v = 0; base_v < n; base_v += CS_WAVE) {
           const int v = base_v + lane;
           int newly = 0;
@@ -826,17 +836,17 @@ __global__ __launch_bounds__(1024, (FW <= 1 && R <= 1 ? 8 : 4)) void cs_propagat
             }
           }
           const u64 nb = __ballot(newly);
-          if (lane == 0 && nb != 0ull) {
+          any_new |= nb;
+          if (!small && lane == 0 && nb != 0ull) {
             nxt[base_v >> 5] |= (unsigned)nb;
             if ((base_v >> 5) + 1 < nw) nxt[(base_v >> 5) + 1] |= (unsigned)(nb >> 32);
           }
         }
         if (__any(fail)) { failed = 1; break; }
         cs_wave_sync();
-        int more = 0;
-        for (int w = 0; w < nw; w++) more |= __builtin_amdgcn_readfirstlane(nxt[w]) != 0u;
-        if (!more) break;
+        if (any_new == 0ull) break; /* ballots are wave-uniform: no LDS read needed */
         rounds++;
+        cur64 = any_new;
         unsigned *t = cur; cur = nxt; nxt = t;
       }
       cs_wave_sync();

@@ -566,11 +566,12 @@ extern "C" int csgpu_model_forbidden_words(const csgpu_model *m) { return m && m
 extern "C" int csgpu_propagate_batch_fb(const csgpu_model *m, const csgpu_val *d_states_in, const uint64_t *d_forb_in,
                                         const csgpu_node *d_nodes, csgpu_val *d_states_out, uint64_t *d_forb_out,
                                         csgpu_result *d_results, int64_t batch, void *stream) {
-  if (m == NULL || d_states_in == NULL || d_nodes == NULL || d_states_out == NULL || d_results == NULL || batch < 0)
-    return set_err(CSGPU_E_ARG, "null argument");
+  if (m == NULL || batch < 0) return set_err(CSGPU_E_ARG, "null argument");
   if (!m->finalized) return set_err(CSGPU_E_STATE, "model is not finalized");
   if (!m->fb_words) return set_err(CSGPU_E_LIMIT, "model does not qualify for the forbidden-set kernel");
   if (batch == 0) return CSGPU_OK;
+  if (d_states_in == NULL || d_nodes == NULL || d_states_out == NULL || d_results == NULL)
+    return set_err(CSGPU_E_ARG, "null argument");
   size_t wg_per_cu = (160u * 1024u) / m->fb_bytes;
   if (wg_per_cu > (size_t)(32 / m->fb_waves)) wg_per_cu = (size_t)(32 / m->fb_waves);
   if (wg_per_cu < 1) wg_per_cu = 1;
@@ -608,10 +609,11 @@ extern "C" int csgpu_propagate_batch(const csgpu_model *m, const csgpu_val *d_st
 extern "C" int csgpu_propagate_batch_obj(const csgpu_model *m, const csgpu_val *d_states_in, const csgpu_node *d_nodes,
                                          csgpu_val *d_states_out, csgpu_result *d_results, int64_t batch,
                                          int32_t obj_lo, int32_t obj_hi, void *stream) {
-  if (m == NULL || d_states_in == NULL || d_nodes == NULL || d_states_out == NULL || d_results == NULL || batch < 0)
-    return set_err(CSGPU_E_ARG, "null argument");
+  if (m == NULL || batch < 0) return set_err(CSGPU_E_ARG, "null argument");
   if (!m->finalized) return set_err(CSGPU_E_STATE, "model is not finalized");
-  if (batch == 0) return CSGPU_OK;
+  if (batch == 0) return CSGPU_OK; /* an empty batch needs no buffers */
+  if (d_states_in == NULL || d_nodes == NULL || d_states_out == NULL || d_results == NULL)
+    return set_err(CSGPU_E_ARG, "null argument");
   const size_t lds = m->slice * CS_WAVES_PER_BLOCK;
   /* resident workgroups per CU: LDS- and wave-slot-limited (32 waves per CU) */
   size_t per_cu = (160u * 1024u) / lds;

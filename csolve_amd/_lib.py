@@ -93,12 +93,14 @@ def load_library():
     L.csgpu_search_free.argtypes = [vp]
     L.csgpu_search_free.restype = None
     L.csgpu_search_put.argtypes = [vp, vp, i64]
+    L.csgpu_search_put_host.argtypes = [vp, vp, i64]
     L.csgpu_search_take.argtypes = [vp, vp, i64, C.POINTER(i64)]
     L.csgpu_search_set_best.argtypes = [vp, i32]
     L.csgpu_search_set_parents.argtypes = [vp, i64]
     L.csgpu_search_set_restart.argtypes = [vp, i64]
     L.csgpu_search_run.argtypes = [vp, i64, C.POINTER(SearchStats)]
     L.csgpu_search_solutions.argtypes = [vp, vp, i64]
+    L.csgpu_search_best_solution.argtypes = [vp, vp]
     L.csgpu_search_solutions.restype = i64
     L.csgpu_propagate_one.argtypes = [vp, vp, Node, vp, C.POINTER(Result)]
     _lib = L

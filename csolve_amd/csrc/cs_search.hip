@@ -38,6 +38,8 @@ struct csgpu_search {
   unsigned long long *d_counters; /* [C_COUNT] */
   int *d_best;
   int32_t *d_solutions;           /* [max_solutions][n] */
+  int32_t *d_best_solution;       /* [n] a solution attaining the incumbent (MIN/MAX) */
+  int have_best_solution;
   int64_t max_solutions;
   csgpu_search_stats st;
   /* restarts (ANY): the states put from outside are kept to restart from */
@@ -278,7 +280,17 @@ __global__ __launch_bounds__(SB) void cs_accept(const cs_val *__restrict__ compl
                                                 unsigned long long *__restrict__ counters,
                                                 int32_t *__restrict__ solutions, long long max_solutions) {
   const int lane = threadIdx.x & 63;
-  const int i = blockIdx.x * (SB / 64) + (threadIdx.x >> 6);
+  int i = blockIdx.x * (SB / 64) + (threadIdx.x >> 6);
+  if (objective == CS_OBJ_ANY) {
+    /* found_any (csolve.c:207-209): exactly one solution is accepted -- the first complete child,
+     * in child order, whose root evaluates to true; one wave does the scan */
+    if (i != 0) return;
+    int first = -1;
+    for (int k = 0; k < count && first < 0; k++)
+      if (truth[k] == 1) first = k;
+    if (first < 0 || counters[C_STORED] != 0ull) return;
+    i = first;
+  }
   if (i >= count || truth[i] != 1) return;
   const cs_val *row = complete + (size_t)i * n;
   long long slot = -1;
@@ -291,6 +303,19 @@ __global__ __launch_bounds__(SB) void cs_accept(const cs_val *__restrict__ compl
   slot = __shfl(slot, 0);
   if (slot < max_solutions)
     for (int v = lane; v < n; v += 64) solutions[(size_t)slot * n + v] = row[v].lo;
+}
+
+/* one wave: the first accepted complete child whose objective value equals the incumbent */
+__global__ void cs_pick_best(const cs_val *__restrict__ complete, const int *__restrict__ truth, int count, int n,
+                             int objective, int obj_var, int best, int32_t *__restrict__ out) {
+  const int lane = threadIdx.x;
+  int pick = -1;
+  for (int k = 0; k < count && pick < 0; k++) {
+    const cs_val o = complete[(size_t)k * n + obj_var];
+    if (truth[k] == 1 && (objective == CS_OBJ_MIN ? o.lo : o.hi) == best) pick = k;
+  }
+  if (pick < 0) return;
+  for (int v = lane; v < n; v += 64) out[v] = complete[(size_t)pick * n + v].lo;
 }
 
 /* move the newest `count` rows into the hole left by taking the oldest ones */
@@ -313,6 +338,7 @@ extern "C" void csgpu_search_free(csgpu_search *s) {
   (void)hipFree(s->d_block_surv); (void)hipFree(s->d_block_comp); (void)hipFree(s->d_surv_off); (void)hipFree(s->d_comp_off);
   (void)hipFree(s->d_counters); (void)hipFree(s->d_best); (void)hipFree(s->d_solutions);
   (void)hipFree(s->seed);
+  (void)hipFree(s->d_best_solution);
   free(s);
 }
 
@@ -390,6 +416,7 @@ extern "C" int csgpu_search_create(const csgpu_model *m, int64_t pool_capacity, 
   ALLOC(s->d_counters, sizeof(unsigned long long) * C_COUNT);
   ALLOC(s->d_best, sizeof(int));
   ALLOC(s->d_solutions, sizeof(int32_t) * (size_t)n * (size_t)s->max_solutions);
+  ALLOC(s->d_best_solution, sizeof(int32_t) * (size_t)n);
 #undef ALLOC
   HIP_OK(hipMemset(s->d_counters, 0, sizeof(unsigned long long) * C_COUNT));
   HIP_OK(hipMemcpy(s->d_best, &s->st.best, sizeof(int), hipMemcpyHostToDevice));
@@ -437,6 +464,18 @@ extern "C" int csgpu_search_put(csgpu_search *s, const csgpu_val *d_states, int6
   s->top += count;
   if (s->top > s->peak) s->peak = s->top;
   return CSGPU_OK;
+}
+
+extern "C" int csgpu_search_put_host(csgpu_search *s, const csgpu_val *states, int64_t count) {
+  if (s == NULL || (count > 0 && states == NULL) || count < 0) return fail(CSGPU_E_ARG, "bad argument");
+  if (count == 0) return CSGPU_OK;
+  cs_val *tmp = NULL;
+  const size_t bytes = (size_t)count * s->n * sizeof(cs_val);
+  HIP_OK(hipMalloc((void **)&tmp, bytes));
+  hipError_t e = hipMemcpy(tmp, states, bytes, hipMemcpyHostToDevice);
+  int rc = e == hipSuccess ? csgpu_search_put(s, (const csgpu_val *)tmp, count) : fail(CSGPU_E_HIP, hipGetErrorString(e));
+  (void)hipFree(tmp);
+  return rc;
 }
 
 extern "C" int csgpu_search_set_restart(csgpu_search *s, int64_t iterations) {
@@ -557,6 +596,11 @@ static int one_iteration(csgpu_search *s) {
     HIP_OK(hipMemcpy(&sol, s->d_counters + C_SOLUTIONS, sizeof sol, hipMemcpyDeviceToHost));
     HIP_OK(hipMemcpy(&best, s->d_best, sizeof best, hipMemcpyDeviceToHost));
     s->st.solutions += sol;
+    if ((s->objective == CS_OBJ_MIN || s->objective == CS_OBJ_MAX) && sol > 0 && best != s->st.best) {
+      hipLaunchKernelGGL(cs_pick_best, dim3(1), dim3(64), 0, 0, s->d_complete_states, s->d_truth, (int)complete, n,
+                         s->objective, s->obj_var, best, s->d_best_solution);
+      s->have_best_solution = 1;
+    }
     s->st.best = best;
   }
   HIP_OK(hipGetLastError());
@@ -606,4 +650,12 @@ extern "C" int64_t csgpu_search_solutions(const csgpu_search *s, int32_t *values
   if (k > 0 && hipMemcpy(values, s->d_solutions, (size_t)k * s->n * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess)
     return CSGPU_E_HIP;
   return k;
+}
+
+extern "C" int csgpu_search_best_solution(const csgpu_search *s, int32_t *values) {
+  if (s == NULL || values == NULL) return CSGPU_E_ARG;
+  if (!s->have_best_solution) return 0;
+  if (hipMemcpy(values, s->d_best_solution, (size_t)s->n * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess)
+    return CSGPU_E_HIP;
+  return 1;
 }

@@ -267,6 +267,12 @@ class Search:
         check(load_library().csgpu_search_run(self._h, max_iterations, C.byref(st)))
         return {k: getattr(st, k) for k, _ in SearchStats._fields_}
 
+    def best_solution(self):
+        """MIN/MAX: values of a solution attaining the incumbent, or None"""
+        out = np.empty(self.model.n_vars, dtype=np.int32)
+        rc = check(load_library().csgpu_search_best_solution(self._h, out.ctypes.data))
+        return out if rc == 1 else None
+
     def solutions(self, max_solutions: int = 1024) -> np.ndarray:
         out = np.empty((max(1, max_solutions), self.model.n_vars), dtype=np.int32)
         k = load_library().csgpu_search_solutions(self._h, out.ctypes.data, max_solutions)

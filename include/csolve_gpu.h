@@ -198,6 +198,8 @@ int csgpu_search_create(const csgpu_model *m, int64_t pool_capacity, int64_t max
 void csgpu_search_free(csgpu_search *s);
 /* append `count` states ([count][n_vars], device memory) to the pool */
 int csgpu_search_put(csgpu_search *s, const csgpu_val *d_states, int64_t count);
+/* the same from host memory (e.g. the root domains of csgpu_model_get_domains) */
+int csgpu_search_put_host(csgpu_search *s, const csgpu_val *states, int64_t count);
 /* remove up to `max` of the OLDEST states (the largest subtrees) into d_states; *count = how many */
 int csgpu_search_take(csgpu_search *s, csgpu_val *d_states, int64_t max, int64_t *count);
 /* cap on the open states expanded per iteration (default: as many as max_children allows for
@@ -215,6 +217,10 @@ int csgpu_search_set_best(csgpu_search *s, int32_t best);
 int csgpu_search_run(csgpu_search *s, int64_t max_iterations, csgpu_search_stats *stats);
 /* copy up to `max` stored solutions ([k][n_vars] values, host memory); returns k */
 int64_t csgpu_search_solutions(const csgpu_search *s, int32_t *values, int64_t max);
+
+/* MIN/MAX: the values ([n_vars], host memory) of a solution that attains the incumbent
+ * (csgpu_search_stats.best); returns 1 if there is one, 0 if no solution was found yet */
+int csgpu_search_best_solution(const csgpu_search *s, int32_t *values);
 
 /* Convenience for single nodes with host buffers (used by the drop-in shim):
  * uploads `state` (n_vars), runs one node, downloads the result.  Synchronous. */

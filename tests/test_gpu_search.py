@@ -57,6 +57,11 @@ def test_optimisation_reaches_the_reference_optimum(name, best):
     assert st["done"] == 1
     assert st["best"] == best
     assert st["solutions"] >= 1
+    # the kept solution attains the optimum and satisfies every constraint
+    row = s.best_solution()
+    assert row is not None and row[model.objective_var] == best
+    truth = model.eval_root(torch.from_numpy(np.stack([row, row], 1)[None].astype(np.int32)).cuda())
+    assert int(truth[0]) == 1
 
 
 def test_search_counters_match_oracle_tree_on_all():
@@ -114,3 +119,26 @@ def test_search_is_reproducible():
     runs = [_solve(problems.queens(40), pool=1 << 20, children=1 << 16, iters=400)[2] for _ in range(3)]
     assert runs[0]["solutions"] >= 1
     assert all(r == runs[0] for r in runs)
+
+
+def test_command_line_front_prints_in_the_reference_format():
+    """csolve_amd/csolve_gpu: reference input conventions, reference output line formats."""
+    import os
+    import re
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "csolve_amd", "csolve_gpu")
+    p = subprocess.run([exe, golden("problems", "queens8_all.txt")], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    lines = p.stdout.strip().split("\n")
+    sols = [l for l in lines if l.startswith("#1: SOLUTION: ")]
+    assert len(sols) == 92 and all(re.fullmatch(r"#1: SOLUTION: (X\d+ = \d+, ){8}BEST: 0", l) for l in sols)
+    assert re.fullmatch(r"#1: CALLS: \d+, CUTS: \d+, PROPS: \d+, CONFL: 0, RESTARTS: \d+, LEVEL: .*SOLUTIONS: 92", lines[-1])
+    p = subprocess.run([exe, golden("problems", "ref_schedule.txt")], capture_output=True, text=True, timeout=120)
+    assert p.stdout.count("SOLUTION: ") == 1 and "end = 11, <obj> = 11, " in p.stdout and "BEST: 11" in p.stdout
+    p = subprocess.run([exe, "-"], input="ANY; x = 1; x = 2;", capture_output=True, text=True, timeout=60)
+    assert p.stdout.strip() == "INFEASIBLE PROBLEM"
+    p = subprocess.run([exe, "-"], input="ANY; x = ;", capture_output=True, text=True, timeout=60)
+    assert p.returncode == 1 and "error: syntax error" in p.stderr and "in line 1" in p.stderr
+    p = subprocess.run([exe, "-"], input="ANY; x != x; 0 <= x; x <= 3;", capture_output=True, text=True, timeout=60)
+    assert "INFEASIBLE PROBLEM" in p.stdout or "NO SOLUTION FOUND" in p.stdout

@@ -92,6 +92,7 @@ def load_library():
     L.csgpu_search_create.argtypes = [vp, i64, i64, C.POINTER(vp)]
     L.csgpu_search_free.argtypes = [vp]
     L.csgpu_search_free.restype = None
+    L.csgpu_search_reset.argtypes = [vp]
     L.csgpu_search_put.argtypes = [vp, vp, i64]
     L.csgpu_search_put_host.argtypes = [vp, vp, i64]
     L.csgpu_search_take.argtypes = [vp, vp, i64, C.POINTER(i64)]

@@ -466,6 +466,22 @@ extern "C" int csgpu_search_put(csgpu_search *s, const csgpu_val *d_states, int6
   return CSGPU_OK;
 }
 
+extern "C" int csgpu_search_reset(csgpu_search *s) {
+  if (s == NULL) return fail(CSGPU_E_ARG, "bad argument");
+  s->top = 0;
+  s->peak = 0;
+  memset(&s->st, 0, sizeof s->st);
+  s->st.best = s->objective == CS_OBJ_MIN ? CS_DOM_MAX : (s->objective == CS_OBJ_MAX ? CS_DOM_MIN : 0);
+  s->seed_count = 0;
+  s->since_restart = 0;
+  s->luby_threshold = 1;
+  s->luby_counter = 1;
+  s->have_best_solution = 0;
+  HIP_OK(hipMemset(s->d_counters, 0, sizeof(unsigned long long) * C_COUNT));
+  HIP_OK(hipMemcpy(s->d_best, &s->st.best, sizeof(int), hipMemcpyHostToDevice));
+  return CSGPU_OK;
+}
+
 extern "C" int csgpu_search_put_host(csgpu_search *s, const csgpu_val *states, int64_t count) {
   if (s == NULL || (count > 0 && states == NULL) || count < 0) return fail(CSGPU_E_ARG, "bad argument");
   if (count == 0) return CSGPU_OK;

@@ -238,6 +238,10 @@ class Search:
         except Exception:
             pass
 
+    def reset(self):
+        """forget pool, statistics, incumbent and seeds; keep the buffers"""
+        check(load_library().csgpu_search_reset(self._h))
+
     def put(self, states: torch.Tensor):
         """append open states [k, n_vars, 2] (device) to the pool"""
         if states.numel() == 0:

@@ -196,6 +196,9 @@ typedef struct csgpu_search_stats {
 /* pool_capacity: states the pool can hold; max_children: children propagated per iteration */
 int csgpu_search_create(const csgpu_model *m, int64_t pool_capacity, int64_t max_children, csgpu_search **out);
 void csgpu_search_free(csgpu_search *s);
+/* forget everything (pool, statistics, incumbent, stored solutions, restart seeds) but keep the
+ * buffers: the engine can run another search on the same model */
+int csgpu_search_reset(csgpu_search *s);
 /* append `count` states ([count][n_vars], device memory) to the pool */
 int csgpu_search_put(csgpu_search *s, const csgpu_val *d_states, int64_t count);
 /* the same from host memory (e.g. the root domains of csgpu_model_get_domains) */

@@ -142,3 +142,16 @@ def test_command_line_front_prints_in_the_reference_format():
     assert p.returncode == 1 and "error: syntax error" in p.stderr and "in line 1" in p.stderr
     p = subprocess.run([exe, "-"], input="ANY; x != x; 0 <= x; x <= 3;", capture_output=True, text=True, timeout=60)
     assert "INFEASIBLE PROBLEM" in p.stdout or "NO SOLUTION FOUND" in p.stdout
+
+
+def test_reset_runs_the_same_search_again():
+    from csolve_amd import problems
+    from csolve_amd.solver import Search, solve_root
+    model = solve_root(problems.queens(9, "ALL"))
+    s = Search(model, 1 << 16, 1 << 12)
+    runs = []
+    for _ in range(2):
+        s.reset()
+        s.put(model.root_state())
+        runs.append(s.run())
+    assert runs[0]["solutions"] == 352 and runs[0] == runs[1]

@@ -256,7 +256,7 @@ def main():
     ap.add_argument("--instances", type=int, default=1 << 18, help="node instances per GPU")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--kernel", type=int, default=0, help="0 best, 1 general, 2 LDS-resident, 3 forbidden-set")
+    ap.add_argument("--kernel", type=int, default=0, help="0 best, 1 general, 2 LDS-resident, 3 forbidden sets in LDS, 4 forbidden sets in registers")
     ap.add_argument("--rebuild-sets", action="store_true", help="forbidden-set kernel without resident sets")
     ap.add_argument("--workload", choices=["propagate", "search"], default="propagate")
     ap.add_argument("--search-queens", type=int, default=13)
@@ -292,14 +292,17 @@ def main():
     n_q = args.queens
     text = problems.queens(n_q)
     model = solve_root(text)
-    # kernel: 0 = best available (forbidden-set kernel with the sets resident next to the states),
-    # 1 general, 2 LDS-resident unit shaving, 3 forbidden-set kernel
+    # kernel: 0 = best available (forbidden-set kernel with the sets resident next to the states, in
+    # registers when the model qualifies), 1 general, 2 LDS-resident unit shaving, 3 / 4 forbidden sets
+    # in LDS / in registers
     fw = model.forbidden_words()
-    use_sets = fw > 0 and args.kernel in (0, 3) and not args.rebuild_sets
-    forced = args.kernel if (args.kernel in (1, 2) or (args.kernel == 3 and not use_sets)) else 0
+    use_sets = fw > 0 and args.kernel in (0, 3, 4) and not args.rebuild_sets
+    forced = args.kernel
     model.set_kernel(forced)
-    kernel_name = "cs_propagate_ne_bitset" if (use_sets or args.kernel == 3) else \
-        {1: "cs_propagate_events", 2: "cs_propagate_ne_lds", 3: "cs_propagate_ne_bitset"}[model.kernel()]
+    if use_sets or args.kernel in (3, 4):
+        kernel_name = "cs_propagate_ne_regs" if (forced in (0, 4) and model.qualifies(4)) else "cs_propagate_ne_bitset"
+    else:
+        kernel_name = {1: "cs_propagate_events", 2: "cs_propagate_ne_lds"}[model.kernel()]
     n = model.n_vars
     info = model.device_info()
 

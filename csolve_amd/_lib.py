@@ -6,7 +6,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcsolve_hip.so")
+LIB_PATH = os.environ.get("CSOLVE_HIP_LIB") or os.path.join(_HERE, "libcsolve_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "csolve_gpu.h")
 
 
@@ -82,6 +82,7 @@ def load_library():
     L.csgpu_model_build_tables.argtypes = [vp]
     L.csgpu_model_eval_clauses_host.argtypes = [vp, vp]
     L.csgpu_model_set_kernel.argtypes = [vp, C.c_int]
+    L.csgpu_model_qualifies.argtypes = [vp, C.c_int]
     L.csgpu_model_get_kernel.argtypes = [vp]
     L.csgpu_propagate_batch.argtypes = [vp, vp, vp, vp, vp, i64, vp]
     L.csgpu_propagate_batch_obj.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, vp]

@@ -43,13 +43,16 @@ struct csgpu_model {
   cs_tables tab;
   size_t slice;      /* LDS bytes per node instance (16-byte aligned) */
   int has_tree_adj;  /* some adjacency entry is a tree clause */
-  int kernel_choice; /* 0 auto, 1 general, 2 LDS-resident */
+  int kernel_choice; /* 0 auto, 1 general, 2 LDS-resident, 3 forbidden sets, 4 forbidden sets in registers */
   void *d_adj_packed;
   int lds_waves;     /* waves per workgroup of the LDS-resident kernel, 0 = not eligible */
   size_t lds_bytes;  /* its dynamic LDS size */
   int fb_words;      /* forbidden-set words per variable (0 = not eligible) */
   int fb_waves;
   size_t fb_bytes;
+  int dense_waves;    /* register-resident forbidden-set kernel: waves per workgroup, 0 = not eligible */
+  size_t dense_bytes; /* its LDS table */
+  void *d_dense_tab;
   int *d_root_lo;
   int *d_sym_off;
   void *d_sym_packed;
@@ -140,8 +143,11 @@ static void free_device(csgpu_model *m) {
   (void)hipFree(m->d_root_lo);
   (void)hipFree(m->d_sym_off);
   (void)hipFree(m->d_sym_packed);
+  (void)hipFree(m->d_dense_tab);
   m->d_sym_off = NULL;
   m->d_sym_packed = NULL;
+  m->d_dense_tab = NULL;
+  m->dense_waves = 0;
   m->d_adj_packed = NULL;
   m->d_root_lo = NULL;
   m->lds_waves = 0;
@@ -391,6 +397,33 @@ static const void *ne_bitset_kernel(int width, int fw, int n_vars) {
 #undef CS_PICK_R
 }
 
+/* register-resident forbidden-set kernel: entry width, set words, variables per lane; the FAST
+ * instantiation (n_vars a multiple of 64 that fills the lanes, both set buffers) keeps D nodes in flight */
+static const void *ne_regs_kernel(int width, int fw, int n_vars, int fast) {
+  const int chunks = (n_vars + CS_WAVE - 1) / CS_WAVE;
+  const int r = chunks <= 1 ? 1 : (chunks <= 2 ? 2 : 4);
+#define CS_PICK_D(E, F, RR)                                                                        \
+  return fast ? (const void *)cs_propagate_ne_regs<E, F, RR, 2, true>                               \
+              : (const void *)cs_propagate_ne_regs<E, F, RR, 1, false>;
+#define CS_PICK_R(E, F)                                                                            \
+  switch (r) {                                                                                     \
+  case 1: CS_PICK_D(E, F, 1)                                                                       \
+  case 2: CS_PICK_D(E, F, 2)                                                                       \
+  default: CS_PICK_D(E, F, 4)                                                                      \
+  }
+#define CS_PICK(E)                                                                                 \
+  switch (fw) {                                                                                    \
+  case 1: CS_PICK_R(E, 1)                                                                          \
+  case 2: CS_PICK_R(E, 2)                                                                          \
+  default: CS_PICK_R(E, 4)                                                                         \
+  }
+  if (width == 1) { CS_PICK(unsigned char) }
+  CS_PICK(unsigned short)
+#undef CS_PICK
+#undef CS_PICK_R
+#undef CS_PICK_D
+}
+
 /* ---- finalize ---------------------------------------------------------------------- */
 
 extern "C" int csgpu_model_build_tables(csgpu_model *m) {
@@ -532,6 +565,24 @@ extern "C" int csgpu_model_finalize(csgpu_model *m) {
                        (int **)&m->d_sym_packed)))
         return rc;
       if ((rc = lds_limit(m->fb_bytes, ne_bitset_kernel(m->img->sym_width, m->fb_words, m->host->n_vars)))) return rc;
+      /* the register-resident variant: the dense table must fit a CU's LDS; the workgroup size that keeps
+       * the most waves resident (32 per CU at most), smaller workgroups on ties */
+      if (m->img->dense_width != 0) {
+        const size_t bytes = (size_t)h->n_vars * m->img->dense_slots * m->img->dense_cols * m->img->dense_width;
+        int best = 0, best_waves = 0;
+        for (int waves = 4; waves <= 16; waves <<= 1) {
+          size_t wgs = (160u * 1024u) / bytes;
+          if (wgs > (size_t)(32 / waves)) wgs = (size_t)(32 / waves);
+          if ((int)wgs * waves > best) { best = (int)wgs * waves; best_waves = waves; }
+        }
+        if (best_waves) {
+          m->dense_waves = best_waves;
+          m->dense_bytes = bytes;
+          if ((rc = upload(m->img->dense_tab, bytes, (int **)&m->d_dense_tab))) return rc;
+          for (int fast = 0; fast <= 1; fast++)
+            if ((rc = lds_limit(bytes, ne_regs_kernel(m->img->dense_width, m->fb_words, h->n_vars, fast)))) return rc;
+        }
+      }
     }
   }
 
@@ -551,14 +602,27 @@ extern "C" int csgpu_model_finalize(csgpu_model *m) {
 }
 
 extern "C" int csgpu_model_set_kernel(csgpu_model *m, int which) {
-  if (m == NULL || which < 0 || which > 3) return set_err(CSGPU_E_ARG, "bad argument");
+  if (m == NULL || which < 0 || which > 4) return set_err(CSGPU_E_ARG, "bad argument");
   if (which >= 2) {
     if (!m->finalized) return set_err(CSGPU_E_STATE, "model is not finalized");
     if (which == 2 && !m->lds_waves) return set_err(CSGPU_E_LIMIT, "model does not qualify for the LDS-resident kernel");
     if (which == 3 && !m->fb_words) return set_err(CSGPU_E_LIMIT, "model does not qualify for the forbidden-set kernel");
+    if (which == 4 && !m->dense_waves)
+      return set_err(CSGPU_E_LIMIT, "model does not qualify for the register-resident forbidden-set kernel");
   }
   m->kernel_choice = which;
   return CSGPU_OK;
+}
+
+extern "C" int csgpu_model_qualifies(const csgpu_model *m, int which) {
+  if (m == NULL || !m->finalized) return 0;
+  switch (which) {
+  case 1: return 1;
+  case 2: return m->lds_waves != 0;
+  case 3: return m->fb_words != 0;
+  case 4: return m->dense_waves != 0;
+  default: return 0;
+  }
 }
 
 extern "C" int csgpu_model_forbidden_words(const csgpu_model *m) { return m && m->finalized ? m->fb_words : 0; }
@@ -572,11 +636,32 @@ extern "C" int csgpu_propagate_batch_fb(const csgpu_model *m, const csgpu_val *d
   if (batch == 0) return CSGPU_OK;
   if (d_states_in == NULL || d_nodes == NULL || d_states_out == NULL || d_results == NULL)
     return set_err(CSGPU_E_ARG, "null argument");
+  const int64_t chunks = (batch + CS_CHUNK - 1) / CS_CHUNK;
+  if (m->dense_waves && m->kernel_choice != 3) {
+    /* register-resident variant (the default when the model qualifies) */
+    size_t wgs = (160u * 1024u) / m->dense_bytes;
+    if (wgs > (size_t)(32 / m->dense_waves)) wgs = (size_t)(32 / m->dense_waves);
+    int64_t g = (int64_t)m->n_cus * (int64_t)wgs;
+    const int64_t need_wg = (chunks + m->dense_waves - 1) / m->dense_waves;
+    g *= 2; /* twice the resident grid: the dispatcher backfills CUs whose waves finish early (measured +1.5 %) */
+    if (g > need_wg) g = need_wg;
+    int n = m->host->n_vars, slots = m->img->dense_slots, dmin_d = m->img->dense_dmin;
+    const void *tab_d = m->d_dense_tab;
+    const int *root_lo_d = m->d_root_lo, *sym_off = m->d_sym_off;
+    long long nb_d = (long long)batch;
+    void *args_d[] = { &n, &tab_d, &slots, &dmin_d, &root_lo_d, &sym_off, &d_states_in, &d_forb_in, &d_nodes,
+                       &d_states_out, &d_forb_out, &d_results, &nb_d };
+    const int chunks_v = (n + CS_WAVE - 1) / CS_WAVE;
+    const int lanes = (chunks_v <= 1 ? 1 : (chunks_v <= 2 ? 2 : 4)) * CS_WAVE;
+    const int fast = n == lanes && d_forb_in != NULL && d_forb_out != NULL;
+    HIP_TRY(hipLaunchKernel(ne_regs_kernel(m->img->dense_width, m->fb_words, n, fast), dim3((unsigned)g),
+                            dim3((unsigned)(m->dense_waves * CS_WAVE)), args_d, m->dense_bytes, (hipStream_t)stream));
+    return CSGPU_OK;
+  }
   size_t wg_per_cu = (160u * 1024u) / m->fb_bytes;
   if (wg_per_cu > (size_t)(32 / m->fb_waves)) wg_per_cu = (size_t)(32 / m->fb_waves);
   if (wg_per_cu < 1) wg_per_cu = 1;
   int64_t grid = (int64_t)m->n_cus * (int64_t)wg_per_cu;
-  const int64_t chunks = (batch + CS_CHUNK - 1) / CS_CHUNK;
   const int64_t need = (chunks + m->fb_waves - 1) / m->fb_waves;
   if (grid > need) grid = need;
   cs_tables tab = m->tab;
@@ -634,7 +719,7 @@ extern "C" int csgpu_propagate_batch_obj(const csgpu_model *m, const csgpu_val *
     tab.obj_lo = obj_lo;
     tab.obj_hi = obj_hi;
   }
-  if (m->kernel_choice == 3 && tab.obj_var < 0)
+  if ((m->kernel_choice == 3 || m->kernel_choice == 4) && tab.obj_var < 0)
     return csgpu_propagate_batch_fb(m, d_states_in, NULL, d_nodes, d_states_out, NULL, d_results, batch, stream);
   if (csgpu_model_get_kernel(m) == 2 && tab.obj_var < 0) {
     /* persistent workgroups: as many as stay resident (LDS- and wave-slot-limited) */

@@ -109,7 +109,7 @@ static int32_t emit_tree(tree_ctx *t, int32_t node) {
 
 void cs_dev_image_free(cs_dev_image *g) {
   if (g == NULL) return;
-  free(g->adj_off); free(g->adj); free(g->clause); free(g->tree_off); free(g->tnode); free(g->tkid); free(g->tree_want); free(g->adj_packed); free(g->sym_off); free(g->sym_packed);
+  free(g->adj_off); free(g->adj); free(g->clause); free(g->tree_off); free(g->tnode); free(g->tkid); free(g->tree_want); free(g->adj_packed); free(g->sym_off); free(g->sym_packed); free(g->dense_tab);
   free(g);
 }
 
@@ -275,6 +275,50 @@ cs_dev_image *cs_dev_image_build(const cs_model *m, int with_lists, const unsign
       free(fill);
     }
     free(cnt);
+    /* dense [u][slot][w] table of the same relation (register-resident kernel) */
+    if (width != 0 && n <= 256) {
+      const int32_t cols = ((n + 63) / 64) * 64;
+      uint8_t *mult = (uint8_t *)calloc((size_t)n * (size_t)n, 1);
+      int slots = 0, ok = 1;
+      for (int32_t c = 0; c < g->n_clauses && ok; c++) {
+        const int32_t *rec = &g->clause[4 * c];
+        if (rec[0] != CS_CL_NE) continue;
+        if (rec[1] == rec[2]) { ok = 0; break; } /* x != x + d is not a pair relation */
+        const int k = ++mult[(size_t)rec[1] * n + rec[2]];
+        mult[(size_t)rec[2] * n + rec[1]] = (uint8_t)k;
+        if (k > slots) slots = k;
+        if (k >= 32) ok = 0;
+      }
+      int64_t cmax = 0;
+      for (int32_t v = 0; v < n; v++) if (m->dom[v].hi > cmax) cmax = m->dom[v].hi;
+      /* the sentinel S must never decode to a bit: c - dmin - S < 0 for every value c, and every real
+       * offset must be below S */
+      const int64_t span = (cmax - dmin64 > dmax64 - dmin64 ? cmax - dmin64 : dmax64 - dmin64);
+      const int dw = span < 255 ? 1 : (span < 65535 ? 2 : 0);
+      if (ok && slots > 0 && dw != 0 && (size_t)n * slots * cols * dw <= 144u * 1024u) {
+        const size_t total = (size_t)n * slots * cols;
+        g->dense_width = dw;
+        g->dense_slots = slots;
+        g->dense_cols = cols;
+        g->dense_dmin = dmin;
+        g->dense_tab = malloc(total * (size_t)dw);
+        memset(g->dense_tab, 0xff, total * (size_t)dw);
+        memset(mult, 0, (size_t)n * (size_t)n);
+        for (int32_t c = 0; c < g->n_clauses; c++) {
+          const int32_t *rec = &g->clause[4 * c];
+          if (rec[0] != CS_CL_NE) continue;
+          const int k = mult[(size_t)rec[1] * n + rec[2]];
+          mult[(size_t)rec[1] * n + rec[2]] = mult[(size_t)rec[2] * n + rec[1]] = (uint8_t)(k + 1);
+          const uint32_t ea = (uint32_t)(rec[3] + m->dom[rec[2]].lo - dmin);  /* pushed by a into b */
+          const uint32_t eb = (uint32_t)(-rec[3] + m->dom[rec[1]].lo - dmin); /* pushed by b into a */
+          const size_t ia = ((size_t)rec[1] * slots + k) * cols + rec[2];
+          const size_t ib = ((size_t)rec[2] * slots + k) * cols + rec[1];
+          if (dw == 1) { ((uint8_t *)g->dense_tab)[ia] = (uint8_t)ea; ((uint8_t *)g->dense_tab)[ib] = (uint8_t)eb; }
+          else { ((uint16_t *)g->dense_tab)[ia] = (uint16_t)ea; ((uint16_t *)g->dense_tab)[ib] = (uint16_t)eb; }
+        }
+      }
+      free(mult);
+    }
   }
   return g;
 }

@@ -72,6 +72,12 @@ typedef struct cs_dev_image {
   int32_t sym_n_adj, sym_width, sym_obits, sym_dmin;
   int32_t *sym_off;     /* [n_vars+1] */
   void *sym_packed;     /* [sym_n_adj] */
+  /* the same symmetric relation as a dense table for models of at most 256 variables (register-resident
+   * kernel): dense_tab[(u * dense_slots + k) * dense_cols + w] = (d + root_lo[w]) - dense_dmin of the k-th
+   * clause between u and w, or the all-ones sentinel; dense_cols = n_vars rounded up to 64.
+   * dense_width = bytes per entry (1 or 2), 0 = not available. */
+  int32_t dense_width, dense_slots, dense_cols, dense_dmin;
+  void *dense_tab;
 } cs_dev_image;
 
 /* with_lists = 0: clause-centric view only (root phase, lists not needed).

@@ -878,6 +878,252 @@ __global__ __launch_bounds__(1024, (FW <= 1 && R <= 1 ? 8 : 4)) void cs_propagat
   }
 }
 
+/* ---- forbidden sets in registers: models of at most 256 variables ---------------------------
+ *
+ * Same algorithm, results and buffers as cs_propagate_ne_bitset, for models whose symmetric
+ * relation fits a dense table tab[u][slot][w] in LDS (cs_device.h).  Lane l owns variables
+ * l, l+64, ... (R of them): bounds and forbidden words stay in VGPRs from the global load to the
+ * global store.  A push by variable u is a conflict-free LDS read of row (u, slot) -- lane w reads
+ * ITS OWN entry, so the sets need no atomics -- and step (2) is pure register arithmetic.  LDS holds
+ * only the table, shared by the workgroup; PROPS of a node is the wave sum of the units shaved
+ * from every variable.  D nodes are in flight per wave (register prefetch).
+ */
+__device__ __forceinline__ int cs_wave_sum(int x) {
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true); /* row_shr:1 */
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true); /* row_shr:2 */
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true); /* row_shr:4 */
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true); /* row_shr:8: lane 15 of a row = row sum */
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, true); /* row_bcast:15 into rows 1 and 3 */
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, true); /* row_bcast:31 into rows 2 and 3 */
+  return __builtin_amdgcn_readlane(x, 63);
+}
+
+/* FAST: n_vars == 64 * R and both set buffers are there -- every load and store of the node loop is
+ * then unconditional straight-line code (a load or store under a branch makes the compiler's s_waitcnt
+ * counts at the join conservative).  FAST stores the (meaningless) row of an inconsistent node too
+ * instead of branching around it.
+ *
+ * No variable 64-bit shifts: the sets are handled as 32-bit words (two per u64).  A first version built
+ * the bit with `1ull << bit` (v_lshlrev_b64) and, with more than one wave per SIMD, produced wrong bits
+ * in a timing-dependent 1-15 % of the nodes of large batches; the same loop with 32-bit shifts, or with
+ * the consumers of the shift moved a few instructions away, is exact (DESIGN.md 3.4 has the
+ * experiments).  tools/validate_k4.py and the large-batch GPU test guard this kernel. */
+template <typename E, int FW, int R, int D, bool FAST>
+__global__ __launch_bounds__(1024, (FW * R <= 1 ? 8 : 4)) void cs_propagate_ne_regs(
+    int n, const E *__restrict__ tab_g, int slots, int dmin, const int *__restrict__ root_lo,
+    const int *__restrict__ sym_off, const cs_val *__restrict__ states_in,
+    const unsigned long long *__restrict__ forb_in, const cs_node_in *__restrict__ nodes,
+    cs_val *__restrict__ states_out, unsigned long long *__restrict__ forb_out, cs_node_out *__restrict__ results,
+    long long batch) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
+  constexpr int W = CS_WAVE * R; /* columns of the table */
+  constexpr int NW = 2 * FW;     /* 32-bit words of forbidden set per variable */
+  const int lane = threadIdx.x & (CS_WAVE - 1);
+  const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); /* keeps row addresses scalar */
+  const int waves_per_block = blockDim.x >> 6;
+  E *s_tab = (E *)cs_lds;
+  {
+    const int vecs = (int)(((size_t)n * slots * W * sizeof(E)) / 16); /* W is a multiple of 64 */
+    const uint4 *src = (const uint4 *)tab_g;
+    uint4 *dst = (uint4 *)cs_lds;
+    for (int i = threadIdx.x; i < vecs; i += blockDim.x) dst[i] = src[i];
+  }
+  __syncthreads();
+
+  int b0[R], deg[R], vcl[R];
+  bool live[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const int v = lane + r * CS_WAVE;
+    live[r] = FAST || v < n;
+    vcl[r] = live[r] ? v : n - 1; /* lanes past the end re-read the last variable and ignore it */
+    b0[r] = live[r] ? root_lo[vcl[r]] : 0;
+    deg[r] = live[r] ? sym_off[vcl[r] + 1] - sym_off[vcl[r]] : 0;
+  }
+  const bool have_in = FAST || forb_in != nullptr;
+  const uint2 *forb_in2 = (const uint2 *)forb_in; /* one u64 = {low word, high word} */
+  uint2 *forb_out2 = (uint2 *)forb_out;
+
+  const long long chunks = (batch + CS_CHUNK - 1) / CS_CHUNK;
+  const long long waves_total = (long long)gridDim.x * waves_per_block;
+  for (long long chunk = (long long)blockIdx.x * waves_per_block + wave_in_block; chunk < chunks; chunk += waves_total) {
+    const long long base = chunk * CS_CHUNK;
+    const int cnt = (int)(batch - base < CS_CHUNK ? batch - base : CS_CHUNK);
+    cs_node_in rec;
+    rec.var = -1; rec.lo = 0; rec.hi = 0; rec.parent = 0;
+    if (lane < cnt) rec = nodes[base + lane];
+    cs_node_out my_result;
+    my_result.status = 0; my_result.props = 0; my_result.revisions = 0; my_result.rounds = 0;
+
+    /* D nodes in flight; a node index past the end of the chunk re-reads the chunk's last node */
+    cs_val pd[D][R];
+    uint2 pf[D][R * FW];
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+      const size_t prow = (size_t)__builtin_amdgcn_readlane(rec.parent, d < cnt ? d : cnt - 1) * n;
+#pragma unroll
+      for (int r = 0; r < R; r++) pd[d][r] = states_in[prow + vcl[r]];
+#pragma unroll
+      for (int q = 0; q < R * FW; q++)
+        pf[d][q] = have_in ? forb_in2[(prow + vcl[q / FW]) * FW + (q % FW)] : make_uint2(0u, 0u);
+    }
+
+    /* the node loop is unrolled D times so that the prefetch registers keep their roles: slot dd is
+     * consumed by node j and refilled for node j + D at the end of that node, nothing is moved */
+    for (int j0 = 0; j0 < cnt; j0 += D) {
+#pragma unroll
+      for (int dd = 0; dd < D; dd++) {
+        const int j = j0 + dd;
+        if (j >= cnt) continue;
+        const int nvar = __builtin_amdgcn_readlane(rec.var, j);
+        const int nlo = __builtin_amdgcn_readlane(rec.lo, j), nhi = __builtin_amdgcn_readlane(rec.hi, j);
+        int lo[R], hi[R];
+        unsigned fb[R][NW]; /* word q of variable r: values b0 + 32 q ... b0 + 32 q + 31 */
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          lo[r] = live[r] ? pd[dd][r].lo : 0;
+          hi[r] = live[r] ? pd[dd][r].hi : 0;
+#pragma unroll
+          for (int k = 0; k < FW; k++) {
+            fb[r][2 * k] = live[r] ? pf[dd][r * FW + k].x : 0u;
+            fb[r][2 * k + 1] = live[r] ? pf[dd][r * FW + k].y : 0u;
+          }
+        }
+
+        /* the assignment (step_enter, csolve.c:294-304) and the first set of variables to push */
+        unsigned long long push[R];
+        const bool all_push = !have_in || nvar < 0;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          if (nvar >= 0 && (nvar >> 6) == r && lane == (nvar & 63)) { lo[r] = nlo; hi[r] = nhi; }
+          if (all_push) push[r] = __ballot(lo[r] == hi[r] && live[r]);
+          else push[r] = (nlo == nhi && (nvar >> 6) == r) ? 1ull << (nvar & 63) : 0ull; /* scalar */
+        }
+        int lo0[R], hi0[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) { lo0[r] = lo[r]; hi0[r] = hi[r]; }
+
+        int rounds = 0, failed = 0, revisions = 0;
+        for (;;) {
+          /* (1) newly valued variables push their forbidden value into the neighbours' sets */
+#pragma unroll
+          for (int r = 0; r < R; r++) {
+            unsigned long long bits = push[r];
+            while (bits != 0ull) {
+              const int ul = __builtin_ctzll(bits);
+              bits &= bits - 1ull;
+              const int cd = __builtin_amdgcn_readlane(lo[r], ul) - dmin;
+              revisions += __builtin_amdgcn_readlane(deg[r], ul);
+              const E *row = s_tab + (size_t)(ul + r * CS_WAVE) * slots * W + lane;
+              /* slots are read three at a time (queens: three clauses per pair); a slot index past the
+               * end re-reads the last one, which is harmless because OR is idempotent */
+              for (int k0 = 0; k0 < slots; k0 += 3) {
+                const int k1 = k0 + 1 < slots ? k0 + 1 : slots - 1, k2 = k0 + 2 < slots ? k0 + 2 : slots - 1;
+                E e[3][R];
+#pragma unroll
+                for (int r2 = 0; r2 < R; r2++) {
+                  e[0][r2] = row[k0 * W + r2 * CS_WAVE];
+                  e[1][r2] = row[k1 * W + r2 * CS_WAVE];
+                  e[2][r2] = row[k2 * W + r2 * CS_WAVE];
+                }
+#pragma unroll
+                for (int g = 0; g < 3; g++) {
+#pragma unroll
+                  for (int r2 = 0; r2 < R; r2++) {
+                    /* the offset includes root_lo of the column; a bit outside [0, 64 FW) (also the
+                     * sentinel) selects no word */
+                    const unsigned bit = (unsigned)(cd - (int)e[g][r2]);
+                    const unsigned sel = bit >> 5, m = 1u << (bit & 31u);
+#pragma unroll
+                    for (int q = 0; q < NW; q++) fb[r2][q] |= sel == (unsigned)q ? m : 0u;
+                  }
+                }
+              }
+            }
+          }
+          /* (2) every variable re-derives its bounds from its set: the lowest allowed value >= lo and
+           * the highest allowed value <= hi, word by word */
+          int fail = 0;
+          unsigned long long any = 0ull;
+#pragma unroll
+          for (int r = 0; r < R; r++) {
+            const int from = lo[r] - b0[r], to = hi[r] - b0[r];
+            int first = 0x7fffffff, last = -1;
+#pragma unroll
+            for (int q = 0; q < NW; q++) {
+              const int f = from - 32 * q, t = to - 32 * q; /* the interval in this word's coordinates */
+              const unsigned mlo = f <= 0 ? ~0u : (f > 31 ? 0u : ~0u << (f & 31));
+              const unsigned mhi = t >= 31 ? ~0u : (t < 0 ? 0u : ~0u >> ((31 - t) & 31));
+              const unsigned a = ~fb[r][q] & mlo & mhi;
+              const int lo_q = a != 0u ? 32 * q + __builtin_ctz(a) : 0x7fffffff;
+              const int hi_q = a != 0u ? 32 * q + 31 - __builtin_clz(a) : -1;
+              first = lo_q < first ? lo_q : first;
+              last = hi_q > last ? hi_q : last;
+            }
+            const bool bad = last < 0; /* no allowed value in [lo, hi] (also when lo > hi) */
+            const int nlo2 = b0[r] + first, nhi2 = b0[r] + last;
+            const bool newly = !bad && (nlo2 != lo[r] || nhi2 != hi[r]) && nlo2 == nhi2;
+            fail |= bad;
+            lo[r] = bad ? lo[r] : nlo2;
+            hi[r] = bad ? hi[r] : nhi2;
+            push[r] = __ballot(newly);
+            any |= push[r];
+          }
+          if (__any(fail)) { failed = 1; break; }
+          if (any == 0ull) break;
+          rounds++;
+        }
+
+        /* refill slot dd for node j + D (after the fixpoint, ahead of the stores) */
+        {
+          const int jn = j + D < cnt ? j + D : cnt - 1;
+          const size_t prow = (size_t)__builtin_amdgcn_readlane(rec.parent, jn) * n;
+#pragma unroll
+          for (int r = 0; r < R; r++) pd[dd][r] = states_in[prow + vcl[r]];
+#pragma unroll
+          for (int q = 0; q < R * FW; q++)
+            pf[dd][q] = have_in ? forb_in2[(prow + vcl[q / FW]) * FW + (q % FW)] : make_uint2(0u, 0u);
+        }
+
+        int open_vars = 0, shaved = 0;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          open_vars += __popcll(__ballot(lo[r] != hi[r]));
+          shaved += (lo[r] - lo0[r]) + (hi0[r] - hi[r]);
+        }
+        const int props = cs_wave_sum(shaved);
+        const size_t orow = (size_t)(base + j) * n;
+        if (FAST) {
+#pragma unroll
+          for (int r = 0; r < R; r++) states_out[orow + lane + r * CS_WAVE] = cs_interval(lo[r], hi[r]);
+#pragma unroll
+          for (int q = 0; q < R * FW; q++)
+            forb_out2[(orow + lane + (q / FW) * CS_WAVE) * FW + (q % FW)] =
+                make_uint2(fb[q / FW][2 * (q % FW)], fb[q / FW][2 * (q % FW) + 1]);
+        } else if (!failed) {
+#pragma unroll
+          for (int r = 0; r < R; r++)
+            if (live[r]) states_out[orow + lane + r * CS_WAVE] = cs_interval(lo[r], hi[r]);
+          if (forb_out != nullptr) {
+#pragma unroll
+            for (int q = 0; q < R * FW; q++)
+              if (live[q / FW])
+                forb_out2[(orow + lane + (q / FW) * CS_WAVE) * FW + (q % FW)] =
+                    make_uint2(fb[q / FW][2 * (q % FW)], fb[q / FW][2 * (q % FW) + 1]);
+          }
+        }
+        if (lane == j) {
+          my_result.status = failed ? -1 : open_vars;
+          my_result.props = props;
+          my_result.revisions = revisions;
+          my_result.rounds = rounds;
+        }
+      }
+    }
+    if (lane < cnt) results[base + lane] = my_result;
+  }
+}
+
 /* ---- full sweeps (root phase): one workgroup per instance ------------------------ */
 
 __global__ __launch_bounds__(CS_BLOCK) void cs_propagate_sweeps(cs_tables T, const cs_val *__restrict__ states_in,

@@ -128,9 +128,13 @@ class Model:
         return self
 
     def set_kernel(self, which: int):
-        """0 automatic, 1 general kernel, 2 LDS-resident kernel (pure binary-NE models that fit)"""
+        """0 automatic, 1 general kernel, 2 LDS-resident unit shaving, 3 forbidden sets in LDS,
+        4 forbidden sets in registers (2-4: pure binary-NE models that fit, see csolve_gpu.h)"""
         check(load_library().csgpu_model_set_kernel(self._h, which))
         return self
+
+    def qualifies(self, which: int) -> bool:
+        return bool(load_library().csgpu_model_qualifies(self._h, which))
 
     def kernel(self) -> int:
         return check(load_library().csgpu_model_get_kernel(self._h))

@@ -119,10 +119,14 @@ int csgpu_model_finalize(csgpu_model *m);
 /* Kernel selection for the batched fixpoint: 0 = automatic (default), 1 = the general kernel
  * (adjacency read through L2; handles tree clauses), 2 = the LDS-resident unit-shaving kernel
  * (pure binary-NE models whose packed adjacency fits in LDS), 3 = the forbidden-set kernel (same
- * models, root intervals of at most 256 values); CSGPU_E_LIMIT if the model does not qualify.
- * All compute the same results; tests run every parity case through each of them.  Automatic:
- * 3 when forbidden-set buffers are passed (csgpu_propagate_batch_fb), else 2, else 1. */
+ * models, root intervals of at most 256 values), 4 = its register-resident variant (additionally
+ * at most 256 variables and a dense pair table that fits in LDS); CSGPU_E_LIMIT if the model does
+ * not qualify.  All compute the same results; tests run every parity case through each of them.
+ * Automatic: csgpu_propagate_batch_fb uses 4 when the model qualifies, else 3;
+ * csgpu_propagate_batch uses 2, else 1. */
 int csgpu_model_set_kernel(csgpu_model *m, int which);
+/* 1 if the finalized model can run kernel `which` (1..4), else 0 */
+int csgpu_model_qualifies(const csgpu_model *m, int which);
 /* which kernel csgpu_propagate_batch will launch: 1, 2 or 3 (see above) */
 int csgpu_model_get_kernel(const csgpu_model *m);
 

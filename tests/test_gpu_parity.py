@@ -25,6 +25,8 @@ def _kernels(model):
         ks.append(2)
     if model.forbidden_words() > 0:
         ks.append(3)  # forbidden-set kernel, sets rebuilt from the incoming state
+    if model.qualifies(4):
+        ks.append(4)  # the same with the sets in registers
     return ks
 
 
@@ -122,6 +124,8 @@ def _random_nodes(rng, states, count):
 @pytest.mark.parametrize("kind,size,kernel", [("queens", 64, 1), ("queens", 64, 2), ("queens", 64, 3),
                                               ("queens", 128, 1), ("queens", 128, 2), ("queens", 128, 3),
                                               ("sudoku", 5, 1), ("sudoku", 5, 2), ("sudoku", 5, 3),
+                                              ("queens", 64, 4), ("queens", 128, 4), ("queens", 100, 4),
+                                              ("sudoku", 3, 4), ("sudoku", 4, 4),
                                               ("schedule", 16, 1)])
 def test_batch_vs_oracle_and_properties(kind, size, kernel):
     """Seeded multi-level batches at the BASELINE sizes: a sample is checked against the oracle
@@ -136,8 +140,9 @@ def test_batch_vs_oracle_and_properties(kind, size, kernel):
     model = solve_root(text)
     model.set_kernel(kernel)
     assert model.kernel() == kernel
-    if kernel == 3:
-        assert model.forbidden_words() == {("queens", 64): 1, ("queens", 128): 2, ("sudoku", 5): 1}[(kind, size)]
+    if kernel >= 3:
+        assert model.forbidden_words() == {("queens", 64): 1, ("queens", 128): 2, ("queens", 100): 2, ("sudoku", 5): 1,
+                                           ("sudoku", 3): 1, ("sudoku", 4): 1}[(kind, size)]
     n = model.n_vars
     omodel = OModel.parse(text)
     omodel.set_domains(model.domains())
@@ -223,8 +228,10 @@ def test_propagate_one_host_path():
             assert (out == walk["after"][i]).all()
 
 
-@pytest.mark.parametrize("kind,size", [("queens", 16), ("queens", 64), ("queens", 128), ("sudoku", 3), ("sudoku", 5)])
-def test_forbidden_sets_inherited_down_a_path(kind, size):
+@pytest.mark.parametrize("kind,size,kernel", [("queens", 16, 3), ("queens", 64, 3), ("queens", 128, 3), ("sudoku", 3, 3),
+                                              ("sudoku", 5, 3), ("queens", 16, 4), ("queens", 64, 4), ("queens", 128, 4),
+                                              ("queens", 100, 4), ("sudoku", 3, 4), ("sudoku", 4, 4)])
+def test_forbidden_sets_inherited_down_a_path(kind, size, kernel):
     """The forbidden-set kernel with the sets carried from parent to child (the search engine's
     mode) against the general kernel and the oracle, five levels deep: same verdicts, same
     domains, same PROPS; and the carried sets equal the sets rebuilt from scratch."""
@@ -235,6 +242,7 @@ def test_forbidden_sets_inherited_down_a_path(kind, size):
     model = solve_root(text)
     fw = model.forbidden_words()
     assert fw > 0
+    model.set_kernel(kernel)  # 3: sets in LDS, 4: sets in registers
     n = model.n_vars
     omodel = OModel.parse(text)
     omodel.set_domains(model.domains())
@@ -253,7 +261,7 @@ def test_forbidden_sets_inherited_down_a_path(kind, size):
         out3, forb3, res3 = model.propagate_fb(states, d_nodes, forb_in=forb)
         model.set_kernel(1)
         out1, res1 = model.propagate(states, d_nodes)
-        model.set_kernel(0)
+        model.set_kernel(kernel)
         torch.cuda.synchronize()
         ok = res1[:, 0] >= 0
         assert torch.equal(res3[:, 0] >= 0, ok)
@@ -280,3 +288,41 @@ def test_forbidden_sets_inherited_down_a_path(kind, size):
         states_h = states.cpu().numpy()
         if len(keep) == 0:
             break
+
+
+@pytest.mark.parametrize("kind,size,count", [("queens", 64, 1 << 17), ("queens", 128, 1 << 16), ("queens", 100, 1 << 15),
+                                             ("sudoku", 4, 1 << 15), ("sudoku", 3, 1 << 15)])
+def test_large_batches_agree_across_kernels(kind, size, count):
+    """Batches large enough that every wave walks through several chunks of nodes under full load
+    (the small parity batches give each wave at most one chunk): the forbidden-set kernels with
+    resident sets (3: LDS, 4: registers, where the model qualifies) against the general kernel on
+    every node -- verdict, fixpoint, PROPS -- and against each other on the carried sets, over
+    repeated launches (a timing-dependent fault shows up as a difference between launches)."""
+    import bench
+    from csolve_amd import problems
+    from csolve_amd.solver import solve_root
+    text = problems.queens(size) if kind == "queens" else problems.sudoku(size, 0.4, 1)
+    model = solve_root(text)
+    assert model.forbidden_words() > 0
+    states_in, nodes, forb_in = bench.make_instances(model, count, seed=99, walks=4096, with_sets=True, restore_kernel=3)
+    model.set_kernel(1)
+    o1, r1 = model.propagate(states_in, nodes)
+    torch.cuda.synchronize()
+    ok = r1[:, 0] >= 0
+    assert 0 < int(ok.sum()) < count
+    sets = {}
+    for k in (3, 4):
+        if not model.qualifies(k):
+            continue
+        model.set_kernel(k)
+        for launch in range(3):
+            o, f, r = model.propagate_fb(states_in, nodes, forb_in=forb_in)
+            torch.cuda.synchronize()
+            assert torch.equal(r[:, 0] >= 0, ok), (k, launch)
+            assert torch.equal(o[ok], o1[ok]), (k, launch)
+            assert torch.equal(r[ok][:, :2], r1[ok][:, :2]), (k, launch)
+            if k in sets:
+                assert torch.equal(f[ok], sets[k]), (k, launch)
+            sets[k] = f[ok]
+    if len(sets) == 2:
+        assert torch.equal(sets[3], sets[4])

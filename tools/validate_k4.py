@@ -1,0 +1,33 @@
+"""Repeated full-batch comparison of the register-resident forbidden-set kernel (4) with the LDS one (3)
+and the general kernel (1) on the bench's instance set: verdicts, states, sets, PROPS of every node."""
+import sys, time, numpy as np, torch
+sys.path.insert(0, ".")
+import bench
+from csolve_amd import problems
+from csolve_amd.solver import solve_root
+nq = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 1 << 18
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+model = solve_root(problems.queens(nq))
+states_in, nodes, forb_in = bench.make_instances(model, count, seed=4242, with_sets=True, restore_kernel=0)
+model.set_kernel(1)
+o1, r1 = model.propagate(states_in, nodes)
+model.set_kernel(3)
+o3, f3, r3 = model.propagate_fb(states_in, nodes, forb_in=forb_in)
+torch.cuda.synchronize()
+ok = r1[:, 0] >= 0
+assert torch.equal(r3[:, 0] >= 0, ok) and torch.equal(o3[ok], o1[ok]) and torch.equal(r3[ok][:, :2], r1[ok][:, :2])
+model.set_kernel(4)
+bad_total = 0
+t0 = time.time()
+for rep in range(reps):
+    o4, f4, r4 = model.propagate_fb(states_in, nodes, forb_in=forb_in)
+    torch.cuda.synchronize()
+    bad = int((~torch.equal(r4[:, 0] >= 0, ok)))
+    v = (r4[:, 0] >= 0) != ok
+    s = ok & ~v & ((o4 != o3).flatten(1).any(1) | (f4 != f3).flatten(1).any(1) | (r4[:, :2] != r3[:, :2]).any(1))
+    nb = int(v.sum()) + int(s.sum())
+    bad_total += nb
+    if nb:
+        print("rep", rep, "verdict mismatches", int(v.sum()), "state/set/props mismatches", int(s.sum()))
+print(f"queens-{nq}: {reps} launches x {count} nodes, mismatching nodes: {bad_total}  ({time.time()-t0:.1f} s)")

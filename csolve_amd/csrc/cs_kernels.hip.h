@@ -659,6 +659,7 @@ __global__ __launch_bounds__(1024, (FW <= 1 && R <= 1 ? 8 : 4)) void cs_propagat
   unsigned char *mine = cs_lds + off_bytes + base_bytes + adj_bytes + wave_in_block * slice_al;
   cs_val *dom = (cs_val *)mine;
   u64 *forb = (u64 *)(dom + n);
+  unsigned *forb32 = (unsigned *)forb; /* the same sets as 32-bit words */
   unsigned *mask_a = (unsigned *)(forb + (size_t)n * FW);
   unsigned *mask_b = mask_a + nw;
   unsigned *pcount = mask_b + nw; /* propagations of the current node */
@@ -789,7 +790,8 @@ __global__ __launch_bounds__(1024, (FW <= 1 && R <= 1 ? 8 : 4)) void cs_propagat
               const unsigned e = s_adj[i];
               const int wv = (int)(e & omask);
               const int bit = c - ((int)(e >> obits) + dmin); /* the offset includes root_lo[wv] */
-              if ((unsigned)bit < (unsigned)(64 * FW)) atomicOr(&forb[wv * FW + (bit >> 6)], 1ull << (bit & 63));
+              /* 32-bit words (no variable 64-bit shifts in this file, see cs_propagate_ne_regs) */
+              if ((unsigned)bit < (unsigned)(64 * FW)) atomicOr(&forb32[wv * (2 * FW) + (bit >> 5)], 1u << (bit & 31));
             }
           }
         }
@@ -809,23 +811,22 @@ __global__ __launch_bounds__(1024, (FW <= 1 && R <= 1 ? 8 : 4)) void cs_propagat
             if (lo > hi) {
               fail = 1;
             } else {
-              /* allowed = values of [lo,hi] that are not forbidden; its lowest / highest member */
-              int nlo2 = 0x7fffffff, nhi2 = (int)0x80000000;
+              /* allowed = values of [lo,hi] that are not forbidden; its lowest / highest member,
+               * word by word (32 values per word) */
+              const int from = lo - b0, to = hi - b0;
+              int first = 0x7fffffff, last = -1;
 #pragma unroll
-              for (int k = 0; k < FW; k++) {
-                const int wlo = b0 + 64 * k; /* value of bit 0 of word k */
-                int from = lo - wlo, to = hi - wlo;
-                if (to < 0 || from > 63) continue;
-                from = from < 0 ? 0 : from;
-                to = to > 63 ? 63 : to;
-                const u64 span = (to - from == 63) ? ~0ull : (((1ull << (to - from + 1)) - 1ull) << from);
-                const u64 allowed = ~forb[v * FW + k] & span;
-                if (allowed != 0ull) {
-                  const int first = wlo + __builtin_ctzll(allowed), last = wlo + 63 - __builtin_clzll(allowed);
-                  nlo2 = first < nlo2 ? first : nlo2;
-                  nhi2 = last > nhi2 ? last : nhi2;
-                }
+              for (int q = 0; q < 2 * FW; q++) {
+                const int f = from - 32 * q, t = to - 32 * q;
+                const unsigned mlo = f <= 0 ? ~0u : (f > 31 ? 0u : ~0u << (f & 31));
+                const unsigned mhi = t >= 31 ? ~0u : (t < 0 ? 0u : ~0u >> ((31 - t) & 31));
+                const unsigned a = ~forb32[v * (2 * FW) + q] & mlo & mhi;
+                const int lo_q = a != 0u ? 32 * q + __builtin_ctz(a) : 0x7fffffff;
+                const int hi_q = a != 0u ? 32 * q + 31 - __builtin_clz(a) : -1;
+                first = lo_q < first ? lo_q : first;
+                last = hi_q > last ? hi_q : last;
               }
+              const int nlo2 = last < 0 ? 0x7fffffff : b0 + first, nhi2 = last < 0 ? (int)0x80000000 : b0 + last;
               if (nlo2 > nhi2) {
                 fail = 1;
               } else if (nlo2 != lo || nhi2 != hi) {

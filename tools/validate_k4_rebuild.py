@@ -1,4 +1,6 @@
-"""Rebuild mode (no incoming sets, every valued variable pushes) of the register-resident forbidden-set kernel\non a full-size batch: states must come back unchanged with zero PROPS, sets equal to the LDS kernel's."""
+"""Rebuild mode (no incoming sets, every valued variable pushes) of the register-resident forbidden-set
+kernel on a full-size batch: states must come back unchanged with zero PROPS, sets equal to the LDS
+kernel's."""
 import sys, numpy as np, torch
 sys.path.insert(0, ".")
 import bench

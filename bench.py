@@ -253,6 +253,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--queens", type=int, default=64)
+    ap.add_argument("--sudoku", type=int, default=0, help="box size N of an N^2 x N^2 sudoku-shaped != network instead of "
+                    "queens (5 = BASELINE configs[2], 25x25)")
     ap.add_argument("--instances", type=int, default=1 << 18, help="node instances per GPU")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
@@ -291,6 +293,10 @@ def main():
 
     n_q = args.queens
     text = problems.queens(n_q)
+    problem_name = f"queens-{n_q} "
+    if args.sudoku:
+        text = problems.sudoku(args.sudoku, 0.3, 1)
+        problem_name = f"sudoku-{args.sudoku ** 2}x{args.sudoku ** 2} (30 % givens) "
     model = solve_root(text)
     # kernel: 0 = best available (forbidden-set kernel with the sets resident next to the states, in
     # registers when the model qualifies), 1 general, 2 LDS-resident unit shaving, 3 / 4 forbidden sets
@@ -374,13 +380,13 @@ def main():
         "vs_baseline": None,
         "dtype": "int32",
         "data": "synthetic",
-        "config": {"workload": f"queens-{n_q} propagation-only fixpoint (BASELINE configs[1]), seeded random-walk "
+        "config": {"workload": f"{problem_name}propagation-only fixpoint (BASELINE configs[{2 if args.sudoku else 1}]), seeded random-walk "
                                f"node instances resident in HBM",
                    "instances_per_gpu": B, "variables": n, "forbidden_sets_resident": bool(use_sets), "clauses": info["ne_clauses"] + info["tree_clauses"],
                    "inconsistent_fraction": fails_all / nodes_all,
                    "props_per_node": props_all / nodes_all, "revisions_per_node": revs_all / nodes_all},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(kernel_name, n_q, B),
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None if args.sudoku else measured_traffic(kernel_name, n_q, B),
                      "kernel": kernel_name, "kernel_ms": kernel_ms,
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "bytes_per_node_instance": alg_bytes // B,

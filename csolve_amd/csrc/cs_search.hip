@@ -17,7 +17,10 @@
 
 #define SB 256 /* threads per block of the bookkeeping kernels */
 
-enum { C_SURVIVORS = 0, C_COMPLETE, C_CUTS, C_PROPS, C_REVS, C_SOLUTIONS, C_STORED, C_TOTAL_CHILDREN, C_COUNT };
+/* device counters.  [C_SURVIVORS, C_PER_ITERATION) are zeroed at the start of every iteration; C_SOLUTIONS and
+ * C_STORED run over the whole search; C_BEST holds the incumbent (an int in the low half) */
+enum { C_SURVIVORS = 0, C_COMPLETE, C_CUTS, C_PROPS, C_REVS, C_TOTAL_CHILDREN, C_PER_ITERATION,
+       C_SOLUTIONS = C_PER_ITERATION, C_STORED, C_BEST, C_COUNT };
 
 struct csgpu_search {
   const csgpu_model *m;
@@ -34,9 +37,10 @@ struct csgpu_search {
   cs_val *d_child_states, *d_complete_states;
   csgpu_result *d_results;
   int *d_dest, *d_complete_list, *d_truth;
-  int *d_block_surv, *d_block_comp, *d_surv_off, *d_comp_off;
+  int *d_block_surv, *d_block_comp, *d_block_cuts, *d_block_props, *d_block_revs, *d_surv_off, *d_comp_off;
   unsigned long long *d_counters; /* [C_COUNT] */
-  int *d_best;
+  int *d_best;                    /* = (int *)&d_counters[C_BEST] */
+  int64_t pending_complete;       /* complete children of the last iteration whose accept results are unread */
   int32_t *d_solutions;           /* [max_solutions][n] */
   int32_t *d_best_solution;       /* [n] a solution attaining the incumbent (MIN/MAX) */
   int have_best_solution;
@@ -50,6 +54,7 @@ struct csgpu_search {
 
 extern "C" int csgpu_internal_set_error(int code, const char *msg); /* cs_capi.hip */
 static int fail(int code, const char *msg) { return csgpu_internal_set_error(code, msg); }
+static int flush_accept_results(csgpu_search *s);
 
 #define SPLIT_WIDTH 256 /* wider intervals are halved instead of enumerated (csolve.c:121-150 style) */
 #define HIP_OK(expr)                                                           \
@@ -93,31 +98,105 @@ __global__ __launch_bounds__(SB) void cs_branch(const cs_val *__restrict__ pool,
   }
 }
 
-/* exclusive scan of child_count[0..parents) by one block; total -> counters[C_TOTAL_CHILDREN] */
-__global__ __launch_bounds__(1024) void cs_scan(const int *__restrict__ count, int parents, int *__restrict__ off,
-                                                unsigned long long *__restrict__ counters, int total_slot) {
-  __shared__ long long part[1024];
-  const int t = threadIdx.x;
-  const int per = (parents + 1023) / 1024;
-  const int b = t * per, e = min(parents, b + per);
-  long long sum = 0;
-  for (int i = b; i < e; i++) sum += count[i];
-  part[t] = sum;
+/* block-wide exclusive scan of one value per thread (1024 threads): wave scan with shuffles, the 16 wave
+ * totals through LDS.  Returns the exclusive prefix; *total = the sum over the block. */
+__device__ __forceinline__ long long cs_block_excl_scan(long long x, long long *s_part, long long *total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  long long incl = x;
+  for (int d = 1; d < 64; d <<= 1) {
+    const long long up = __shfl_up(incl, d);
+    if (lane >= d) incl += up;
+  }
+  if (lane == 63) s_part[wave] = incl;
   __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1) {
-    long long v = t >= d ? part[t - d] : 0;
-    __syncthreads();
-    part[t] += v;
-    __syncthreads();
+  long long before = 0, all = 0;
+  for (int w = 0; w < 16; w++) {
+    const long long p = s_part[w];
+    before += w < wave ? p : 0;
+    all += p;
   }
-  long long run = part[t] - sum;
-  for (int i = b; i < e; i++) {
-    off[i] = (int)run;
-    run += count[i];
+  __syncthreads();
+  *total = all;
+  return before + incl - x;
+}
+
+/* exclusive scan of count[0..items) by one block; every thread takes SCAN_PER consecutive elements of a
+ * tile (vector loads), the per-thread sums go through the block scan; total -> off[items] and
+ * counters[total_slot].  count and off are 16-byte aligned (hipMalloc), the tail is handled one by one. */
+#define SCAN_PER 16
+__global__ __launch_bounds__(1024) void cs_scan(const int *__restrict__ count, int items, int *__restrict__ off,
+                                                unsigned long long *__restrict__ counters, int total_slot) {
+  __shared__ long long s_part[16];
+  long long carry = 0;
+  for (int base = 0; base < items; base += 1024 * SCAN_PER) {
+    const int first = base + (int)threadIdx.x * SCAN_PER;
+    int x[SCAN_PER];
+    if (first + SCAN_PER <= items) {
+#pragma unroll
+      for (int q = 0; q < SCAN_PER / 4; q++) {
+        const int4 v = ((const int4 *)(count + first))[q];
+        x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < SCAN_PER; q++) x[q] = first + q < items ? count[first + q] : 0;
+    }
+    int sum = 0;
+#pragma unroll
+    for (int q = 0; q < SCAN_PER; q++) { const int v = x[q]; x[q] = sum; sum += v; } /* exclusive within the thread */
+    long long total;
+    const long long ex = carry + cs_block_excl_scan((long long)sum, s_part, &total);
+    if (first + SCAN_PER <= items) {
+#pragma unroll
+      for (int q = 0; q < SCAN_PER / 4; q++)
+        ((int4 *)(off + first))[q] = make_int4((int)ex + x[4 * q], (int)ex + x[4 * q + 1], (int)ex + x[4 * q + 2], (int)ex + x[4 * q + 3]);
+    } else {
+#pragma unroll
+      for (int q = 0; q < SCAN_PER; q++)
+        if (first + q < items) off[first + q] = (int)ex + x[q];
+    }
+    carry += total;
   }
-  if (t == 1023) {
-    off[parents] = (int)part[1023];
-    counters[total_slot] = (unsigned long long)part[1023];
+  if (threadIdx.x == 0) {
+    off[items] = (int)carry;
+    counters[total_slot] = (unsigned long long)carry;
+  }
+}
+
+/* the per-block class counts of cs_classify_count: exclusive scans of the survivors and of the complete
+ * children, sums of cuts / propagations / revisions -> counters */
+__global__ __launch_bounds__(1024) void cs_scan_classes(const int *__restrict__ block_surv, const int *__restrict__ block_comp,
+                                                        const int *__restrict__ block_cuts, const int *__restrict__ block_props,
+                                                        const int *__restrict__ block_revs, int blocks,
+                                                        int *__restrict__ surv_off, int *__restrict__ comp_off,
+                                                        unsigned long long *__restrict__ counters) {
+  __shared__ long long s_part[16];
+  long long carry_s = 0, carry_c = 0, cuts = 0, props = 0, revs = 0;
+  for (int base = 0; base < blocks; base += 1024) {
+    const int i = base + (int)threadIdx.x;
+    const bool in = i < blocks;
+    long long total;
+    const long long es = cs_block_excl_scan(in ? block_surv[i] : 0, s_part, &total);
+    if (in) surv_off[i] = (int)(carry_s + es);
+    carry_s += total;
+    const long long ec = cs_block_excl_scan(in ? block_comp[i] : 0, s_part, &total);
+    if (in) comp_off[i] = (int)(carry_c + ec);
+    carry_c += total;
+    (void)cs_block_excl_scan(in ? block_cuts[i] : 0, s_part, &total);
+    cuts += total;
+    (void)cs_block_excl_scan(in ? block_props[i] : 0, s_part, &total);
+    props += total;
+    (void)cs_block_excl_scan(in ? block_revs[i] : 0, s_part, &total);
+    revs += total;
+  }
+  if (threadIdx.x == 0) {
+    surv_off[blocks] = (int)carry_s;
+    comp_off[blocks] = (int)carry_c;
+    counters[C_SURVIVORS] = (unsigned long long)carry_s;
+    counters[C_COMPLETE] = (unsigned long long)carry_c;
+    counters[C_CUTS] = (unsigned long long)cuts;
+    counters[C_PROPS] = (unsigned long long)props;
+    counters[C_REVS] = (unsigned long long)revs;
   }
 }
 
@@ -172,8 +251,9 @@ __global__ __launch_bounds__(SB) void cs_emit(const cs_val *__restrict__ pool, l
  * workgroup finished first, so a search is reproducible run to run. */
 __global__ __launch_bounds__(SB) void cs_classify_count(const csgpu_result *__restrict__ res, int children,
                                                         int *__restrict__ block_surv, int *__restrict__ block_comp,
-                                                        unsigned long long *__restrict__ counters) {
-  __shared__ unsigned long long s_sum[5];
+                                                        int *__restrict__ block_cuts, int *__restrict__ block_props,
+                                                        int *__restrict__ block_revs) {
+  __shared__ int s_sum[5][SB / 64];
   const int t = threadIdx.x, i = blockIdx.x * SB + t;
   int status = -2, props = 0, revs = 0;
   if (i < children) {
@@ -181,10 +261,7 @@ __global__ __launch_bounds__(SB) void cs_classify_count(const csgpu_result *__re
     props = res[i].props;
     revs = res[i].revisions;
   }
-  if (t < 5) s_sum[t] = 0ull;
-  __syncthreads();
-  unsigned long long ps = status > 0, pk = status == 0, pc = status == -1, pp = (unsigned long long)props,
-                     pr = (unsigned long long)revs;
+  int ps = status > 0, pk = status == 0, pc = status == -1, pp = props, pr = revs;
   for (int o = 32; o > 0; o >>= 1) {
     ps += __shfl_xor(ps, o);
     pk += __shfl_xor(pk, o);
@@ -193,19 +270,14 @@ __global__ __launch_bounds__(SB) void cs_classify_count(const csgpu_result *__re
     pr += __shfl_xor(pr, o);
   }
   if ((t & 63) == 0) {
-    atomicAdd(&s_sum[0], ps);
-    atomicAdd(&s_sum[1], pk);
-    atomicAdd(&s_sum[2], pc);
-    atomicAdd(&s_sum[3], pp);
-    atomicAdd(&s_sum[4], pr);
+    s_sum[0][t >> 6] = ps; s_sum[1][t >> 6] = pk; s_sum[2][t >> 6] = pc; s_sum[3][t >> 6] = pp; s_sum[4][t >> 6] = pr;
   }
   __syncthreads();
-  if (t == 0) {
-    block_surv[blockIdx.x] = (int)s_sum[0];
-    block_comp[blockIdx.x] = (int)s_sum[1];
-    atomicAdd(&counters[C_CUTS], s_sum[2]); /* sums do not depend on the order */
-    atomicAdd(&counters[C_PROPS], s_sum[3]);
-    atomicAdd(&counters[C_REVS], s_sum[4]);
+  if (t < 5) {
+    int v = 0;
+    for (int w = 0; w < SB / 64; w++) v += s_sum[t][w];
+    int *dst = t == 0 ? block_surv : (t == 1 ? block_comp : (t == 2 ? block_cuts : (t == 3 ? block_props : block_revs)));
+    dst[blockIdx.x] = v; /* folded by cs_scan_classes: sums do not depend on any order */
   }
 }
 
@@ -274,35 +346,56 @@ __global__ __launch_bounds__(SB) void cs_gather_complete(const cs_val *__restric
   for (int v = lane; v < n; v += 64) dst[v] = src[v];
 }
 
-/* accept the complete children whose root evaluated to true: count, incumbent, store some */
+/* accept the complete children whose root evaluated to true: count, incumbent, store some.
+ * One thread per complete child; one atomic per wave for the count and the incumbent. */
 __global__ __launch_bounds__(SB) void cs_accept(const cs_val *__restrict__ complete, const int *__restrict__ truth,
-                                                int count, int n, int objective, int obj_var, int *__restrict__ best,
+                                                int count, int n, int objective, int obj_var,
                                                 unsigned long long *__restrict__ counters,
                                                 int32_t *__restrict__ solutions, long long max_solutions) {
   const int lane = threadIdx.x & 63;
-  int i = blockIdx.x * (SB / 64) + (threadIdx.x >> 6);
+  int i = blockIdx.x * SB + threadIdx.x;
   if (objective == CS_OBJ_ANY) {
     /* found_any (csolve.c:207-209): exactly one solution is accepted -- the first complete child,
-     * in child order, whose root evaluates to true; one wave does the scan */
+     * in child order, whose root evaluates to true; one thread does the scan */
     if (i != 0) return;
     int first = -1;
     for (int k = 0; k < count && first < 0; k++)
       if (truth[k] == 1) first = k;
     if (first < 0 || counters[C_STORED] != 0ull) return;
-    i = first;
+    counters[C_SOLUTIONS] += 1ull;
+    counters[C_STORED] = 1ull;
+    for (int v = 0; v < n; v++) solutions[v] = complete[(size_t)first * n + v].lo;
+    return;
   }
-  if (i >= count || truth[i] != 1) return;
-  const cs_val *row = complete + (size_t)i * n;
-  long long slot = -1;
-  if (lane == 0) {
-    atomicAdd(&counters[C_SOLUTIONS], 1ull);
-    if (objective == CS_OBJ_MIN) atomicMin(best, row[obj_var].lo);
-    if (objective == CS_OBJ_MAX) atomicMax(best, row[obj_var].hi);
-    slot = (long long)atomicAdd(&counters[C_STORED], 1ull); /* which solutions are kept may vary; their count does not */
+  const bool ok = i < count && truth[i] == 1;
+  const unsigned long long mask = __ballot(ok);
+  if (mask == 0ull) return;
+  const int accepted = __popcll(mask), leader = __builtin_ctzll(mask);
+  if (objective == CS_OBJ_MIN || objective == CS_OBJ_MAX) {
+    int val = objective == CS_OBJ_MIN ? 0x7fffffff : (int)0x80000000;
+    if (ok) val = objective == CS_OBJ_MIN ? complete[(size_t)i * n + obj_var].lo : complete[(size_t)i * n + obj_var].hi;
+    for (int o = 32; o > 0; o >>= 1) {
+      const int other = __shfl_xor(val, o);
+      val = objective == CS_OBJ_MIN ? (other < val ? other : val) : (other > val ? other : val);
+    }
+    if (lane == leader) {
+      if (objective == CS_OBJ_MIN) atomicMin((int *)&counters[C_BEST], val);
+      else atomicMax((int *)&counters[C_BEST], val);
+    }
   }
-  slot = __shfl(slot, 0);
-  if (slot < max_solutions)
-    for (int v = lane; v < n; v += 64) solutions[(size_t)slot * n + v] = row[v].lo;
+  long long slot0 = max_solutions;
+  if (lane == leader) {
+    atomicAdd(&counters[C_SOLUTIONS], (unsigned long long)accepted);
+    /* which solutions are kept may vary; their count does not.  Once the store is full nobody asks for a slot */
+    if (counters[C_STORED] < (unsigned long long)max_solutions)
+      slot0 = (long long)atomicAdd(&counters[C_STORED], (unsigned long long)accepted);
+  }
+  slot0 = __shfl(slot0, leader);
+  if (ok) {
+    const long long slot = slot0 + __popcll(mask & ((1ull << lane) - 1ull));
+    if (slot < max_solutions)
+      for (int v = 0; v < n; v++) solutions[(size_t)slot * n + v] = complete[(size_t)i * n + v].lo;
+  }
 }
 
 /* one wave: the first accepted complete child whose objective value equals the incumbent */
@@ -336,7 +429,8 @@ extern "C" void csgpu_search_free(csgpu_search *s) {
   (void)hipFree(s->d_nodes); (void)hipFree(s->d_child_states); (void)hipFree(s->d_complete_states);
   (void)hipFree(s->d_results); (void)hipFree(s->d_dest); (void)hipFree(s->d_complete_list); (void)hipFree(s->d_truth);
   (void)hipFree(s->d_block_surv); (void)hipFree(s->d_block_comp); (void)hipFree(s->d_surv_off); (void)hipFree(s->d_comp_off);
-  (void)hipFree(s->d_counters); (void)hipFree(s->d_best); (void)hipFree(s->d_solutions);
+  (void)hipFree(s->d_block_cuts); (void)hipFree(s->d_block_props); (void)hipFree(s->d_block_revs);
+  (void)hipFree(s->d_counters); (void)hipFree(s->d_solutions);
   (void)hipFree(s->seed);
   (void)hipFree(s->d_best_solution);
   free(s);
@@ -410,11 +504,14 @@ extern "C" int csgpu_search_create(const csgpu_model *m, int64_t pool_capacity, 
     const size_t blocks = ((size_t)max_children + SB - 1) / SB + 1;
     ALLOC(s->d_block_surv, sizeof(int) * blocks);
     ALLOC(s->d_block_comp, sizeof(int) * blocks);
+    ALLOC(s->d_block_cuts, sizeof(int) * blocks);
+    ALLOC(s->d_block_props, sizeof(int) * blocks);
+    ALLOC(s->d_block_revs, sizeof(int) * blocks);
     ALLOC(s->d_surv_off, sizeof(int) * (blocks + 1));
     ALLOC(s->d_comp_off, sizeof(int) * (blocks + 1));
   }
   ALLOC(s->d_counters, sizeof(unsigned long long) * C_COUNT);
-  ALLOC(s->d_best, sizeof(int));
+  s->d_best = (int *)(s->d_counters + C_BEST);
   ALLOC(s->d_solutions, sizeof(int32_t) * (size_t)n * (size_t)s->max_solutions);
   ALLOC(s->d_best_solution, sizeof(int32_t) * (size_t)n);
 #undef ALLOC
@@ -477,6 +574,7 @@ extern "C" int csgpu_search_reset(csgpu_search *s) {
   s->luby_threshold = 1;
   s->luby_counter = 1;
   s->have_best_solution = 0;
+  s->pending_complete = 0;
   HIP_OK(hipMemset(s->d_counters, 0, sizeof(unsigned long long) * C_COUNT));
   HIP_OK(hipMemcpy(s->d_best, &s->st.best, sizeof(int), hipMemcpyHostToDevice));
   return CSGPU_OK;
@@ -529,12 +627,39 @@ extern "C" int csgpu_search_set_parents(csgpu_search *s, int64_t parents_per_ite
 
 extern "C" int csgpu_search_set_best(csgpu_search *s, int32_t best) {
   if (s == NULL) return fail(CSGPU_E_ARG, "bad argument");
+  const int rcf = flush_accept_results(s); /* an unread incumbent of the last iteration must not be overwritten */
+  if (rcf != CSGPU_OK) return rcf;
   int better = (s->objective == CS_OBJ_MIN && best < s->st.best) || (s->objective == CS_OBJ_MAX && best > s->st.best);
   if (better) {
     s->st.best = best;
     HIP_OK(hipMemcpy(s->d_best, &best, sizeof(int), hipMemcpyHostToDevice));
   }
   return CSGPU_OK;
+}
+
+/* the accept kernel's results, read one host round trip later than they were produced */
+static int apply_accept_results(csgpu_search *s, unsigned long long solutions_total, int best) {
+  if (s->pending_complete == 0) return CSGPU_OK;
+  const int improved = (s->objective == CS_OBJ_MIN || s->objective == CS_OBJ_MAX) && solutions_total > s->st.solutions &&
+                       best != s->st.best;
+  s->st.solutions = solutions_total;
+  if (improved) {
+    /* the complete children and their truth values of that iteration are still in place */
+    hipLaunchKernelGGL(cs_pick_best, dim3(1), dim3(64), 0, 0, s->d_complete_states, s->d_truth, (int)s->pending_complete,
+                       s->n, s->objective, s->obj_var, best, s->d_best_solution);
+    s->have_best_solution = 1;
+  }
+  if (s->objective == CS_OBJ_MIN || s->objective == CS_OBJ_MAX) s->st.best = best;
+  s->pending_complete = 0;
+  HIP_OK(hipGetLastError());
+  return CSGPU_OK;
+}
+
+static int flush_accept_results(csgpu_search *s) {
+  if (s->pending_complete == 0) return CSGPU_OK;
+  unsigned long long tail[C_COUNT - C_SOLUTIONS];
+  HIP_OK(hipMemcpy(tail, s->d_counters + C_SOLUTIONS, sizeof tail, hipMemcpyDeviceToHost));
+  return apply_accept_results(s, tail[0], (int)(unsigned)tail[C_BEST - C_SOLUTIONS]);
 }
 
 static int one_iteration(csgpu_search *s) {
@@ -547,15 +672,19 @@ static int one_iteration(csgpu_search *s) {
   }
   const long long first_row = s->top - parents;
   if (parents == 0) return CSGPU_OK;
-  HIP_OK(hipMemsetAsync(s->d_counters, 0, sizeof(unsigned long long) * C_STORED, 0));
+  HIP_OK(hipMemsetAsync(s->d_counters, 0, sizeof(unsigned long long) * C_PER_ITERATION, 0));
   const unsigned pb = (unsigned)((parents + 3) / 4);
   hipLaunchKernelGGL(cs_branch, dim3(pb), dim3(SB), 0, 0, s->pool, first_row, (int)parents, n, s->d_branch_var,
                      s->d_child_count);
   hipLaunchKernelGGL(cs_scan, dim3(1), dim3(1024), 0, 0, s->d_child_count, (int)parents, s->d_child_off, s->d_counters,
                      (int)C_TOTAL_CHILDREN);
-  unsigned long long total = 0;
-  HIP_OK(hipMemcpy(&total, s->d_counters + C_TOTAL_CHILDREN, sizeof total, hipMemcpyDeviceToHost));
-  const int64_t children = (int64_t)total;
+  /* first host read of the iteration: the number of children, and with it what the previous
+   * iteration's accept left behind (solutions so far, incumbent) */
+  unsigned long long head[C_COUNT - C_TOTAL_CHILDREN];
+  HIP_OK(hipMemcpy(head, s->d_counters + C_TOTAL_CHILDREN, sizeof head, hipMemcpyDeviceToHost));
+  const int64_t children = (int64_t)head[0];
+  int rc0 = apply_accept_results(s, head[C_SOLUTIONS - C_TOTAL_CHILDREN], (int)(unsigned)head[C_BEST - C_TOTAL_CHILDREN]);
+  if (rc0 != CSGPU_OK) return rc0;
   if (children > s->max_children) return fail(CSGPU_E_LIMIT, "internal: more children than the batch buffers hold");
   hipLaunchKernelGGL(cs_emit, dim3(pb), dim3(SB), 0, 0, s->pool, first_row, (int)parents, n, s->d_branch_var,
                      s->d_child_off, s->d_nodes, s->objective == CS_OBJ_MAX ? 0 : 1,
@@ -579,16 +708,14 @@ static int one_iteration(csgpu_search *s) {
   if (rc != CSGPU_OK) return rc;
   const unsigned cb = (unsigned)((children + SB - 1) / SB), cw = (unsigned)((children + 3) / 4);
   hipLaunchKernelGGL(cs_classify_count, dim3(cb), dim3(SB), 0, 0, s->d_results, (int)children, s->d_block_surv,
-                     s->d_block_comp, s->d_counters);
-  hipLaunchKernelGGL(cs_scan, dim3(1), dim3(1024), 0, 0, s->d_block_surv, (int)cb, s->d_surv_off, s->d_counters,
-                     (int)C_SURVIVORS);
-  hipLaunchKernelGGL(cs_scan, dim3(1), dim3(1024), 0, 0, s->d_block_comp, (int)cb, s->d_comp_off, s->d_counters,
-                     (int)C_COMPLETE);
+                     s->d_block_comp, s->d_block_cuts, s->d_block_props, s->d_block_revs);
+  hipLaunchKernelGGL(cs_scan_classes, dim3(1), dim3(1024), 0, 0, s->d_block_surv, s->d_block_comp, s->d_block_cuts,
+                     s->d_block_props, s->d_block_revs, (int)cb, s->d_surv_off, s->d_comp_off, s->d_counters);
   hipLaunchKernelGGL(cs_classify_assign, dim3(cb), dim3(SB), 0, 0, s->d_results, (int)children, (long long)s->top,
                      s->d_surv_off, s->d_comp_off, s->d_dest, s->d_complete_list);
   hipLaunchKernelGGL(cs_scatter, dim3(cw), dim3(SB), 0, 0, s->d_child_states, s->d_dest, (int)children, n, s->pool,
                      s->d_child_forb, s->pool_forb, s->fw);
-  unsigned long long c[C_COUNT];
+  unsigned long long c[C_PER_ITERATION];
   HIP_OK(hipMemcpy(c, s->d_counters, sizeof c, hipMemcpyDeviceToHost));
   s->top += (int64_t)c[C_SURVIVORS];
   if (s->top > s->peak) s->peak = s->top;
@@ -604,20 +731,16 @@ static int one_iteration(csgpu_search *s) {
                        (int)complete, n, s->d_complete_states);
     rc = csgpu_eval_batch(s->m, (const csgpu_val *)s->d_complete_states, s->d_truth, complete, NULL);
     if (rc != CSGPU_OK) return rc;
-    hipLaunchKernelGGL(cs_accept, dim3(gw), dim3(SB), 0, 0, s->d_complete_states, s->d_truth, (int)complete, n,
-                       s->objective, s->obj_var, s->d_best, s->d_counters, s->d_solutions,
+    hipLaunchKernelGGL(cs_accept, dim3((unsigned)((complete + SB - 1) / SB)), dim3(SB), 0, 0, s->d_complete_states,
+                       s->d_truth, (int)complete, n, s->objective, s->obj_var, s->d_counters, s->d_solutions,
                        (long long)s->max_solutions);
-    unsigned long long sol = 0;
-    int best = 0;
-    HIP_OK(hipMemcpy(&sol, s->d_counters + C_SOLUTIONS, sizeof sol, hipMemcpyDeviceToHost));
-    HIP_OK(hipMemcpy(&best, s->d_best, sizeof best, hipMemcpyDeviceToHost));
-    s->st.solutions += sol;
-    if ((s->objective == CS_OBJ_MIN || s->objective == CS_OBJ_MAX) && sol > 0 && best != s->st.best) {
-      hipLaunchKernelGGL(cs_pick_best, dim3(1), dim3(64), 0, 0, s->d_complete_states, s->d_truth, (int)complete, n,
-                         s->objective, s->obj_var, best, s->d_best_solution);
-      s->have_best_solution = 1;
+    /* what accept found is read together with the next iteration's child count (or at the end of the
+     * run); ANY stops on the first solution, so it looks at once */
+    s->pending_complete = complete;
+    if (s->objective == CS_OBJ_ANY) {
+      rc = flush_accept_results(s);
+      if (rc != CSGPU_OK) return rc;
     }
-    s->st.best = best;
   }
   HIP_OK(hipGetLastError());
   return CSGPU_OK;
@@ -648,6 +771,10 @@ extern "C" int csgpu_search_run(csgpu_search *s, int64_t max_iterations, csgpu_s
       s->restart_base = keep;
       if (rc != CSGPU_OK) return rc;
     }
+  }
+  {
+    const int rcf = flush_accept_results(s);
+    if (rcf != CSGPU_OK) return rcf;
   }
   s->st.pool = s->top;
   s->st.pool_peak = s->peak;

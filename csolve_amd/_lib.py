@@ -83,6 +83,8 @@ def load_library():
     L.csgpu_model_eval_clauses_host.argtypes = [vp, vp]
     L.csgpu_model_set_kernel.argtypes = [vp, C.c_int]
     L.csgpu_model_qualifies.argtypes = [vp, C.c_int]
+    L.csgpu_set_linear_fast_paths.argtypes = [C.c_int]
+    L.csgpu_set_linear_fast_paths.restype = None
     L.csgpu_model_get_kernel.argtypes = [vp]
     L.csgpu_propagate_batch.argtypes = [vp, vp, vp, vp, vp, i64, vp]
     L.csgpu_propagate_batch_obj.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, vp]

@@ -39,7 +39,7 @@ struct csgpu_model {
   int finalized;
   cs_dev_image *img; /* search image */
   /* device copies of the image */
-  int *d_adj_off, *d_adj, *d_clause, *d_tree_off, *d_tnode, *d_tkid, *d_tree_want;
+  int *d_adj_off, *d_adj, *d_clause, *d_tree_off, *d_tnode, *d_tkid, *d_tree_want, *d_lit;
   cs_tables tab;
   size_t slice;      /* LDS bytes per node instance (16-byte aligned) */
   int has_tree_adj;  /* some adjacency entry is a tree clause */
@@ -138,7 +138,9 @@ extern "C" cs_model *csgpu_model_host(csgpu_model *m) { return m ? m->host : NUL
 static void free_device(csgpu_model *m) {
   (void)hipFree(m->d_adj_off); (void)hipFree(m->d_adj); (void)hipFree(m->d_clause);
   (void)hipFree(m->d_tree_off); (void)hipFree(m->d_tnode); (void)hipFree(m->d_tkid); (void)hipFree(m->d_tree_want);
+  (void)hipFree(m->d_lit);
   m->d_tree_want = NULL;
+  m->d_lit = NULL;
   (void)hipFree(m->d_adj_packed);
   (void)hipFree(m->d_root_lo);
   (void)hipFree(m->d_sym_off);
@@ -195,6 +197,8 @@ extern "C" int csgpu_model_set_domains(csgpu_model *m, const csgpu_val *in) {
   return CSGPU_OK;
 }
 
+extern "C" void csgpu_set_linear_fast_paths(int on) { cs_dev_linear_fast_paths = on != 0; }
+
 extern "C" int csgpu_model_device_info(const csgpu_model *m, int64_t info[8]) {
   if (m == NULL || info == NULL) return set_err(CSGPU_E_ARG, "null argument");
   if (m->img == NULL) return set_err(CSGPU_E_STATE, "device tables are not built");
@@ -212,7 +216,7 @@ extern "C" int csgpu_model_device_info(const csgpu_model *m, int64_t info[8]) {
 /* ---- device image ------------------------------------------------------------------ */
 
 struct dev_tables_owner {
-  int *adj_off, *adj, *clause, *tree_off, *tnode, *tkid, *tree_want;
+  int *adj_off, *adj, *clause, *tree_off, *tnode, *tkid, *tree_want, *lit;
 };
 
 static int upload(const void *src, size_t bytes, int **dst) {
@@ -231,6 +235,7 @@ static int upload_image(const cs_dev_image *g, dev_tables_owner *o, cs_tables *t
   if ((rc = upload(g->tnode, (size_t)(g->n_tnodes ? g->n_tnodes : 1) * 16, &o->tnode))) return rc;
   if ((rc = upload(g->tkid, (size_t)(g->n_tkids ? g->n_tkids : 1) * 4, &o->tkid))) return rc;
   if ((rc = upload(g->tree_want, (size_t)(g->n_trees ? g->n_trees : 1) * 8, &o->tree_want))) return rc;
+  if ((rc = upload(g->lit, (size_t)(g->n_lits ? g->n_lits : 1) * 16, &o->lit))) return rc;
   t->n_vars = g->n_vars;
   t->n_clauses = g->n_clauses;
   t->n_words = (g->n_vars + 31) / 32;
@@ -241,6 +246,7 @@ static int upload_image(const cs_dev_image *g, dev_tables_owner *o, cs_tables *t
   t->tnode = (const int4 *)o->tnode;
   t->tkid = o->tkid;
   t->tree_want = (const int2 *)o->tree_want;
+  t->lit = (const int4 *)o->lit;
   t->obj_var = -1;
   t->obj_lo = CS_DOM_MIN;
   t->obj_hi = CS_DOM_MAX;
@@ -250,6 +256,7 @@ static int upload_image(const cs_dev_image *g, dev_tables_owner *o, cs_tables *t
 static void free_tables(dev_tables_owner *o) {
   (void)hipFree(o->adj_off); (void)hipFree(o->adj); (void)hipFree(o->clause);
   (void)hipFree(o->tree_off); (void)hipFree(o->tnode); (void)hipFree(o->tkid); (void)hipFree(o->tree_want);
+  (void)hipFree(o->lit);
 }
 
 static int lds_limit(size_t bytes, const void *func) {
@@ -493,13 +500,14 @@ extern "C" int csgpu_model_finalize(csgpu_model *m) {
   }
   m->d_adj_off = own.adj_off; m->d_adj = own.adj; m->d_clause = own.clause;
   m->d_tree_off = own.tree_off; m->d_tnode = own.tnode; m->d_tkid = own.tkid; m->d_tree_want = own.tree_want;
+  m->d_lit = own.lit;
   if (rc != CSGPU_OK) return rc;
 
   const size_t slice = (size_t)h->n_vars * sizeof(cs_val) + 2 * (size_t)m->tab.n_words * sizeof(unsigned);
   m->slice = (slice + 15) & ~(size_t)15;
   m->has_tree_adj = 0;
   for (int32_t i = 0; i < m->img->n_adj; i++)
-    if (m->img->adj[2 * i] < 0) { m->has_tree_adj = 1; break; }
+    if (m->img->adj[2 * i] < 0 && m->img->adj[2 * i + 1] == 0) { m->has_tree_adj = 1; break; }
   const size_t lds = m->slice * CS_WAVES_PER_BLOCK;
   if ((rc = lds_limit(lds, (const void *)cs_propagate_events<false>))) return rc;
   if ((rc = lds_limit(lds, (const void *)cs_propagate_events<true>))) return rc;

@@ -60,6 +60,58 @@ static int match_ne(const cs_model *m, int32_t root, int32_t *a, int32_t *b, int
   return 1;
 }
 
+int cs_dev_linear_fast_paths = 1;
+
+/* node == X_var (bounds anything but a sentinel: the linear paths compute in 64 bits, and a bare variable
+ * is never summed by the reference) or X_var + k with everything small */
+static int affine_wide(const cs_model *m, int32_t node, int32_t *var, int64_t *k) {
+  const cs_node *n = &m->nodes[node];
+  if (n->op == CS_OP_VAR) {
+    cs_val d = m->dom[n->a];
+    if (d.lo == CS_DOM_MIN || d.hi == CS_DOM_MAX) return 0;
+    *var = n->a; *k = 0;
+    return 1;
+  }
+  /* VAR + constant: as on the NE path everything must be small, so that the reference's saturating sum
+   * (arith.c:38-51) is the plain sum */
+  if (n->op == CS_OP_ADD) return affine(m, node, var, k);
+  return 0;
+}
+
+/* a literal "X_a < X_b + d" from LT(L, R) (negated = 0) or NOT(LT(L, R)) (negated = 1: R <= L, i.e.
+ * X_rb < X_la + (ka - kb + 1)) */
+static int lt_literal(const cs_model *m, int32_t lt_node, int negated, int32_t *a, int32_t *b, int32_t *d) {
+  const cs_node *e = &m->nodes[lt_node];
+  if (e->op != CS_OP_LT) return 0;
+  int32_t va, vb;
+  int64_t ka, kb;
+  if (!affine_wide(m, e->a, &va, &ka) || !affine_wide(m, e->b, &vb, &kb) || va == vb) return 0;
+  const int64_t dd = negated ? ka - kb + 1 : kb - ka;
+  if (!small(dd)) return 0;
+  if (negated) { *a = vb; *b = va; } else { *a = va; *b = vb; }
+  *d = (int32_t)dd;
+  return 1;
+}
+
+/* LT / NOT(LT) with the polarity the clause is wanted in */
+static int match_lt(const cs_model *m, int32_t root, int want_true, int32_t *a, int32_t *b, int32_t *d) {
+  const cs_node *n = &m->nodes[root];
+  if (n->op == CS_OP_LT) return lt_literal(m, root, !want_true, a, b, d);
+  if (n->op == CS_OP_NOT) return lt_literal(m, n->a, want_true, a, b, d);
+  return 0;
+}
+
+/* EQ(L, R) wanted true: X_a = X_b + d */
+static int match_eq(const cs_model *m, int32_t root, int32_t *a, int32_t *b, int32_t *d) {
+  const cs_node *e = &m->nodes[root];
+  if (e->op != CS_OP_EQ) return 0;
+  int64_t ka, kb;
+  if (!affine_wide(m, e->a, a, &ka) || !affine_wide(m, e->b, b, &kb) || *a == *b) return 0;
+  if (!small(kb - ka)) return 0;
+  *d = (int32_t)(kb - ka);
+  return 1;
+}
+
 typedef struct {
   const cs_model *m;
   ibuf tnode, tkid;
@@ -109,7 +161,7 @@ static int32_t emit_tree(tree_ctx *t, int32_t node) {
 
 void cs_dev_image_free(cs_dev_image *g) {
   if (g == NULL) return;
-  free(g->adj_off); free(g->adj); free(g->clause); free(g->tree_off); free(g->tnode); free(g->tkid); free(g->tree_want); free(g->adj_packed); free(g->sym_off); free(g->sym_packed); free(g->dense_tab);
+  free(g->adj_off); free(g->adj); free(g->clause); free(g->tree_off); free(g->tnode); free(g->tkid); free(g->tree_want); free(g->lit); free(g->adj_packed); free(g->sym_off); free(g->sym_packed); free(g->dense_tab);
   free(g);
 }
 
@@ -118,6 +170,10 @@ cs_dev_image *cs_dev_image_build(const cs_model *m, int with_lists, const unsign
   if (m->clause_node == NULL || (with_lists && m->list_off == NULL)) {
     if (err) snprintf(err, errlen, "model has no clause index");
     return NULL;
+  }
+  {
+    const char *e = getenv("CSGPU_LINEAR_FAST_PATHS"); /* "0" switches the linear fast paths off (debugging) */
+    if (e != NULL && e[0] == '0') cs_dev_linear_fast_paths = 0;
   }
   cs_dev_image *g = (cs_dev_image *)calloc(1, sizeof *g);
   g->n_vars = m->n_vars;
@@ -131,6 +187,7 @@ cs_dev_image *cs_dev_image_build(const cs_model *m, int with_lists, const unsign
   for (int32_t i = 0; i < m->n_nodes; i++) t.local[i] = -1;
   ibuf tree_off = { 0 };
   ibuf want = { 0 };
+  ibuf lits = { 0 };
 
   for (int32_t c = 0; c < m->n_clauses; c++) {
     int32_t root = m->clause_node[c];
@@ -144,7 +201,25 @@ cs_dev_image *cs_dev_image_build(const cs_model *m, int with_lists, const unsign
     } else if (want_true && match_ne(m, root, &a, &b, &d)) {
       rec[0] = CS_CL_NE; rec[1] = a; rec[2] = b; rec[3] = d;
       g->n_ne++;
+    } else if (cs_dev_linear_fast_paths && want_true && match_eq(m, root, &a, &b, &d)) {
+      rec[0] = CS_CL_EQ; rec[1] = a; rec[2] = b; rec[3] = d;
+      g->n_lin++;
+    } else if (cs_dev_linear_fast_paths && (want_true || (m->clause_want[c].lo == 0 && m->clause_want[c].hi == 0)) &&
+               match_lt(m, root, want_true, &a, &b, &d)) {
+      rec[0] = CS_CL_LT; rec[1] = a; rec[2] = b; rec[3] = d;
+      g->n_lin++;
+    } else if (cs_dev_linear_fast_paths && want_true && rn->op == CS_OP_OR) {
+      int32_t a2, b2, d2;
+      if (match_lt(m, rn->a, 1, &a, &b, &d) && match_lt(m, rn->b, 1, &a2, &b2, &d2)) {
+        rec[0] = CS_CL_OR2; rec[1] = lits.n / 4;
+        ibuf_push(&lits, a); ibuf_push(&lits, b); ibuf_push(&lits, d); ibuf_push(&lits, 0);
+        ibuf_push(&lits, a2); ibuf_push(&lits, b2); ibuf_push(&lits, d2); ibuf_push(&lits, 0);
+        g->n_or2++;
+      } else {
+        goto as_tree;
+      }
     } else {
+    as_tree:
       ibuf_push(&tree_off, t.tnode.n / 4);
       t.base = t.tnode.n / 4;
       t.touched.n = 0;
@@ -166,6 +241,8 @@ cs_dev_image *cs_dev_image_build(const cs_model *m, int with_lists, const unsign
   g->tkid = t.tkid.v ? t.tkid.v : (int32_t *)calloc(1, sizeof(int32_t));
   g->n_tkids = t.tkid.n;
   g->tree_want = want.v ? want.v : (int32_t *)calloc(2, sizeof(int32_t));
+  g->lit = lits.v ? lits.v : (int32_t *)calloc(4, sizeof(int32_t));
+  g->n_lits = lits.n / 4;
   free(t.local);
   free(t.touched.v);
 
@@ -190,6 +267,14 @@ cs_dev_image *cs_dev_image_build(const cs_model *m, int with_lists, const unsign
         if (rec[0] == CS_CL_NE) {
           if (rec[1] == v) { ibuf_push(&adj, rec[2]); ibuf_push(&adj, rec[3]); }
           else { ibuf_push(&adj, rec[1]); ibuf_push(&adj, -rec[3]); }
+        } else if (rec[0] == CS_CL_EQ) { /* X_a = X_b + d  <=>  X_b = X_a - d */
+          if (rec[1] == v) { ibuf_push(&adj, rec[2] | (CS_REL_EQ << 28)); ibuf_push(&adj, rec[3]); }
+          else { ibuf_push(&adj, rec[1] | (CS_REL_EQ << 28)); ibuf_push(&adj, -rec[3]); }
+        } else if (rec[0] == CS_CL_LT) { /* X_a < X_b + d  <=>  X_b > X_a - d */
+          if (rec[1] == v) { ibuf_push(&adj, rec[2] | (CS_REL_LT << 28)); ibuf_push(&adj, rec[3]); }
+          else { ibuf_push(&adj, rec[1] | (CS_REL_GT << 28)); ibuf_push(&adj, -rec[3]); }
+        } else if (rec[0] == CS_CL_OR2) {
+          ibuf_push(&adj, ~rec[1]); ibuf_push(&adj, 1);
         } else if (rec[0] == CS_CL_TREE) {
           ibuf_push(&adj, ~rec[1]); ibuf_push(&adj, 0);
         }
@@ -201,7 +286,7 @@ cs_dev_image *cs_dev_image_build(const cs_model *m, int with_lists, const unsign
     g->n_adj = adj.n / 2;
     g->adj = adj.v ? adj.v : (int32_t *)calloc(2, sizeof(int32_t));
     /* packed copy for the LDS-resident kernel: only for pure binary-NE adjacency */
-    if (g->n_tree_clauses == 0 && g->n_adj > 0) {
+    if (g->n_tree_clauses == 0 && g->n_lin == 0 && g->n_or2 == 0 && g->n_adj > 0) {
       int32_t dmin = g->adj[1], dmax = g->adj[1];
       for (int32_t i = 0; i < g->n_adj; i++) {
         if (g->adj[2 * i + 1] < dmin) dmin = g->adj[2 * i + 1];
@@ -226,7 +311,7 @@ cs_dev_image *cs_dev_image_build(const cs_model *m, int with_lists, const unsign
   } else {
     g->adj = (int32_t *)calloc(2, sizeof(int32_t));
   }
-  if (with_lists && g->n_tree_clauses == 0 && g->n_ne > 0) {
+  if (with_lists && g->n_tree_clauses == 0 && g->n_lin == 0 && g->n_or2 == 0 && g->n_ne > 0) {
     /* symmetric lists straight from the clause records */
     const int32_t n = m->n_vars;
     int32_t *cnt = (int32_t *)calloc((size_t)n + 1, sizeof(int32_t));

@@ -11,12 +11,16 @@
  *          CS_CL_SKIP  constant-true element, never narrows, never fails
  *          CS_CL_NE    X_a != X_b + d   (binary fast path, see below)
  *          CS_CL_TREE  general expression tree, a = tree id
+ *          CS_CL_EQ    X_a  = X_b + d   (linear fast paths, see below)
+ *          CS_CL_LT    X_a  < X_b + d
+ *          CS_CL_OR2   lit[a] or lit[a+1], each literal {a, b, d, 0}: X_a < X_b + d
  *
  *  (2) variable-centric, for the event-driven fixpoint (propagate.c:488-538):
  *        adj_off[v] .. adj_off[v+1]   entries {x, y} of variable v, in the order of
  *        the reference's per-variable clause list (parser_support.c:338-396)
- *          x >= 0 : binary NE seen from v:  X_v != X_x + y
- *          x <  0 : tree clause, tree id = ~x
+ *          x >= 0 : binary relation seen from v, other variable = x & 0x0fffffff, relation = x >> 28:
+ *                   0  X_v != X_o + y     1  X_v = X_o + y     2  X_v < X_o + y     3  X_v > X_o + y
+ *          x <  0 : y == 0: tree clause, tree id = ~x;  y == 1: two-literal disjunction, first literal = ~x
  *
  * Binary fast path.  A clause NOT(EQ(L, R)) where L and R are each `VAR` or
  * `VAR + constant` (constant on either side of the ADD, possibly written as a NEG of
@@ -26,6 +30,14 @@
  * record is exactly equivalent to revising the tree through propagate_not ->
  * propagate_eq(false) -> propagate_add -> propagate_term (propagate.c:289-301, 123-136,
  * 106-120, 223-246, 57-87).
+ *
+ * Linear fast paths (schedule.txt-style models: precedences `s + d <= t`, definitions `e = s + d`,
+ * disjunctive resources `a > b | c > d`).  A clause EQ(L, R), LT(L, R), NOT(LT(L, R)) or
+ * OR(literal, literal) whose L and R are `VAR` or `VAR + constant` over two different variables, under
+ * the same magnitude limits as the NE path, is stored in the normal form above (NOT(LT(L,R)) becomes
+ * R < L + 1) and revised by bound propagation: exactly what propagate_eq / propagate_lt / propagate_not /
+ * propagate_or / propagate_add push down to the two variables (propagate.c:139-246, 289-340).  Tests
+ * compare these paths with the tree interpreter on the same models (csgpu_model_set_fast_paths).
  *
  * Trees.  tree_off[t] .. tree_off[t+1] index tnode[], 4 ints per node { op, a, b, 0 } in
  * post-order (children before parents, the root last); child references are indices local
@@ -41,7 +53,9 @@
 extern "C" {
 #endif
 
-enum { CS_CL_SKIP = 0, CS_CL_NE = 1, CS_CL_TREE = 2 };
+enum { CS_CL_SKIP = 0, CS_CL_NE = 1, CS_CL_TREE = 2, CS_CL_EQ = 3, CS_CL_LT = 4, CS_CL_OR2 = 5 };
+enum { CS_REL_NE = 0, CS_REL_EQ = 1, CS_REL_LT = 2, CS_REL_GT = 3 };
+#define CS_ADJ_VAR_MASK 0x0fffffff
 
 /* largest tree a device lane can revise (per-lane value scratch), and the deepest
  * pending-push stack it keeps */
@@ -51,6 +65,9 @@ typedef struct cs_dev_image {
   int32_t n_vars, n_clauses;
   int32_t n_adj;        /* adjacency entries */
   int32_t n_ne, n_tree_clauses, n_skip;
+  int32_t n_lin, n_or2;  /* EQ/LT clauses, two-literal disjunctions */
+  int32_t n_lits;
+  int32_t *lit;         /* [4*n_lits] {a, b, d, 0}: X_a < X_b + d */
   int32_t max_list;     /* longest per-variable list */
   int32_t *adj_off;     /* [n_vars+1] */
   int32_t *adj;         /* [2*n_adj] */
@@ -86,6 +103,9 @@ typedef struct cs_dev_image {
  * can never narrow or fail again; it is stored as CS_CL_SKIP and left out of the adjacency.
  * (The reference reaches the same effect by folding the clause to the constant 1 in its
  * root normalisation pass, reference src/normalize.c:67-75 via parser.y:66.) */
+/* 1 (default): EQ / LT / two-literal OR clauses take the linear fast paths; 0: they stay trees (tests) */
+extern int cs_dev_linear_fast_paths;
+
 cs_dev_image *cs_dev_image_build(const cs_model *m, int with_lists, const unsigned char *entailed, char *err,
                                  size_t errlen);
 void cs_dev_image_free(cs_dev_image *img);

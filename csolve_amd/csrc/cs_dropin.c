@@ -182,6 +182,8 @@ static struct constr_t *g_root;   /* last root passed to propagate() */
 static struct env_t *g_env;
 static size_t g_size;
 static csgpu_model *g_model;      /* attached search model */
+static int g_trace = -1;           /* CSOLVE_DROPIN_TRACE=1: entry points on stderr */
+#define TRACE(...) do { if (g_trace < 0) g_trace = getenv("CSOLVE_DROPIN_TRACE") != NULL; if (g_trace) { fprintf(stderr, __VA_ARGS__); fflush(stderr); } } while (0)
 static csgpu_val *g_state, *g_out;
 static uint64_t g_calls[4];
 
@@ -200,6 +202,7 @@ void csolve_dropin_detach(void) {
 }
 
 static int attach(struct env_t *env, size_t size, struct constr_t *root, int at_root) {
+  TRACE("[dropin] attach size=%zu at_root=%d\n", size, at_root);
   csolve_dropin_detach();
   flat f;
   memset(&f, 0, sizeof f);
@@ -246,6 +249,7 @@ static int attach(struct env_t *env, size_t size, struct constr_t *root, int at_
   g_root = root;
   g_state = (csgpu_val *)malloc((size ? size : 1) * sizeof *g_state);
   g_out = (csgpu_val *)malloc((size ? size : 1) * sizeof *g_out);
+  TRACE("[dropin] attached\n");
   return 0;
 }
 
@@ -311,7 +315,9 @@ prop_result_t propagate_clauses(const struct clause_list_t *clauses) {
   csgpu_node node = { var, g_state[var].lo, g_state[var].hi, 0 };
   csgpu_result res;
   g_calls[0]++;
+  TRACE("[dropin] propagate_clauses var=%d [%d,%d]\n", node.var, node.lo, node.hi);
   if (csgpu_propagate_one(g_model, g_state, node, g_out, &res) != CSGPU_OK) fatal_gpu("propagate_clauses");
+  TRACE("[dropin]   -> status %d props %d rounds %d\n", res.status, res.props, res.rounds);
   props += (uint64_t)res.props; /* narrowings of an inconsistent node count too (propagate.c:78) */
   if (res.status < 0) return PROP_ERROR;
   for (size_t i = 0; i < g_size; i++)
@@ -340,7 +346,9 @@ static prop_result_t propagate_tree(struct constr_t *constr, struct val_t want, 
     for (int32_t c = 0; c < hm->n_clauses; c++) hm->clause_want[c] = cs_interval(want.lo, want.hi);
   }
   int32_t status = 0;
+  TRACE("[dropin] tree propagate, %d clauses\n", hm->n_clauses);
   if (csgpu_model_root_propagate(gm, &status) != CSGPU_OK) fatal_gpu("propagate");
+  TRACE("[dropin]   -> %d\n", status);
   prop_result_t total = status;
   struct env_t **changed = NULL;
   size_t n_changed = 0;

@@ -51,6 +51,7 @@ struct cs_tables {
   const int4 *tnode;
   const int *tkid;
   const int2 *tree_want;
+  const int4 *lit; /* literals {a, b, d, 0} of the two-literal disjunctions: X_a < X_b + d */
   /* objective bound applied to every node before it is propagated (objective_update_val,
    * reference src/objective.c:101-126): dom[obj_var] is intersected with [obj_lo, obj_hi] */
   int obj_var, obj_lo, obj_hi;
@@ -111,6 +112,62 @@ struct cs_ctx {
 };
 
 /* X_u != X_w + d seen from u (both directions of the clause, propagate.c:123-136) */
+/* X_a < X_b + d pushed down to the two variables (propagate_lt true + propagate_add, propagate.c:139-200,
+ * 223-246): hi_a <= hi_b + d - 1, lo_b >= lo_a - d + 1.  Bounds are not sentinels and |d| < 2^30
+ * (cs_device.h), the arithmetic is done in 64 bits: a bound that would leave the int32 range cannot
+ * narrow anything, which is also what the saturating tree path makes of it. */
+__device__ __forceinline__ void cs_lt_enforce(cs_ctx &cx, int a, int b, int d) {
+  const cs_val da = cx.dom[a], db = cx.dom[b];
+  const long long ha = (long long)db.hi + d - 1, lb = (long long)da.lo - d + 1;
+  if (ha < da.lo || lb > db.hi) { cx.fail = 1; return; }
+  if (ha < da.hi) cx.lower_hi(a, (int)ha);
+  if (lb > db.lo) cx.raise_lo(b, (int)lb);
+}
+
+__device__ __forceinline__ cs_val cs_shifted(cs_val v, int d) { /* [v.lo + d, v.hi + d] clamped to int32 */
+  const long long lo = (long long)v.lo + d, hi = (long long)v.hi + d;
+  return cs_interval(lo < CS_DOM_MIN ? CS_DOM_MIN : (lo > CS_DOM_MAX ? CS_DOM_MAX : (int)lo),
+                     hi < CS_DOM_MIN ? CS_DOM_MIN : (hi > CS_DOM_MAX ? CS_DOM_MAX : (int)hi));
+}
+
+/* three-valued X_a < X_b + d and X_a = X_b + d in 64 bits (no bound is a sentinel on these paths; the shift by
+ * d, which for a negated LT is an artefact of the normal form, must not create one) */
+__device__ __forceinline__ cs_val cs_ev_lt_shifted(cs_val a, cs_val b, int d) {
+  return cs_tv((long long)a.hi < (long long)b.lo + d, (long long)a.lo >= (long long)b.hi + d);
+}
+__device__ __forceinline__ cs_val cs_ev_eq_shifted(cs_val a, cs_val b, int d) {
+  return cs_tv(a.lo == a.hi && (long long)a.lo == (long long)b.lo + d && (long long)a.hi == (long long)b.hi + d,
+               (long long)a.hi < (long long)b.lo + d || (long long)a.lo > (long long)b.hi + d);
+}
+
+/* binary relation seen from u: rel 0  X_u != X_w + d, 1  X_u = X_w + d, 2  X_u < X_w + d, 3  X_u > X_w + d */
+__device__ __forceinline__ void cs_ne_revise(cs_ctx &cx, int u, int w, int d);
+__device__ __forceinline__ void cs_lin_revise(cs_ctx &cx, int u, int w, int d, int rel) {
+  if (rel == CS_REL_NE) { cs_ne_revise(cx, u, w, d); return; }
+  cx.revisions++;
+  if (rel == CS_REL_EQ) { /* propagate_eq true: each side into the other's interval */
+    const cs_val du = cx.dom[u], dw = cx.dom[w];
+    cx.narrow(u, cs_shifted(dw, d));
+    if (!cx.fail) cx.narrow(w, cs_shifted(du, -d));
+  } else if (rel == CS_REL_LT) {
+    cs_lt_enforce(cx, u, w, d);
+  } else { /* X_u > X_w + d  <=>  X_w < X_u - d */
+    cs_lt_enforce(cx, w, u, -d);
+  }
+}
+
+/* lit[0] or lit[1] wanted true (propagate_or, propagate.c:318-340): a literal that cannot hold any more
+ * forces the other one; a literal is X_a < X_b + d */
+__device__ __forceinline__ void cs_or2_revise(cs_ctx &cx, const int4 *lit) {
+  cx.revisions++;
+  const int4 l0 = lit[0], l1 = lit[1];
+  const bool f0 = (long long)cx.dom[l0.x].lo >= (long long)cx.dom[l0.y].hi + l0.z; /* X_a >= X_b + d for sure */
+  const bool f1 = (long long)cx.dom[l1.x].lo >= (long long)cx.dom[l1.y].hi + l1.z;
+  if (f0 && f1) cx.fail = 1;
+  else if (f0) cs_lt_enforce(cx, l1.x, l1.y, l1.z);
+  else if (f1) cs_lt_enforce(cx, l0.x, l0.y, l0.z);
+}
+
 __device__ __forceinline__ void cs_ne_revise(cs_ctx &cx, int u, int w, int d) {
   cs_val du = cx.dom[u], dw = cx.dom[w];
   cx.revisions++;
@@ -365,7 +422,9 @@ __global__ __launch_bounds__(CS_BLOCK) void cs_propagate_events(cs_tables T, con
           for (int i = beg + lane; i < end && !cx.fail; i += CS_WAVE) {
             const int2 e = T.adj[i];
             if (e.x >= 0) {
-              cs_ne_revise(cx, u, e.x, e.y);
+              cs_lin_revise(cx, u, e.x & CS_ADJ_VAR_MASK, e.y, e.x >> 28);
+            } else if (e.y != 0) {
+              cs_or2_revise(cx, T.lit + ~e.x);
             } else if (HAS_TREE) {
               cs_tree_scratch S;
               cs_tree_revise(T, ~e.x, cx, S);
@@ -1153,6 +1212,10 @@ __global__ __launch_bounds__(CS_BLOCK) void cs_propagate_sweeps(cs_tables T, con
       const int4 rec = T.clause[c];
       if (rec.x == CS_CL_NE) {
         cs_ne_revise(cx, rec.y, rec.z, rec.w);
+      } else if (rec.x == CS_CL_EQ || rec.x == CS_CL_LT) {
+        cs_lin_revise(cx, rec.y, rec.z, rec.w, rec.x == CS_CL_EQ ? CS_REL_EQ : CS_REL_LT);
+      } else if (rec.x == CS_CL_OR2) {
+        cs_or2_revise(cx, T.lit + rec.y);
       } else if (rec.x == CS_CL_TREE) {
         cs_tree_scratch S;
         cs_tree_revise(T, rec.y, cx, S);
@@ -1209,6 +1272,15 @@ __global__ __launch_bounds__(CS_BLOCK) void cs_eval_root(cs_tables T, const cs_v
       b.lo += rec.w;
       b.hi += rec.w;
       v = cs_ev_not(cs_ev_eq(a, b));
+    } else if (rec.x == CS_CL_EQ || rec.x == CS_CL_LT) {
+      v = rec.x == CS_CL_EQ ? cs_ev_eq_shifted(dom[rec.y], dom[rec.z], rec.w) : cs_ev_lt_shifted(dom[rec.y], dom[rec.z], rec.w);
+    } else if (rec.x == CS_CL_OR2) {
+      cs_val t[2];
+      for (int k = 0; k < 2; k++) {
+        const int4 l = T.lit[rec.y + k];
+        t[k] = cs_ev_lt_shifted(dom[l.x], dom[l.y], l.z);
+      }
+      v = cs_ev_or(t[0], t[1]);
     } else if (rec.x == CS_CL_TREE) {
       cs_tree_scratch S;
       const int base = T.tree_off[rec.y], len = T.tree_off[rec.y + 1] - base;
@@ -1240,6 +1312,15 @@ __global__ __launch_bounds__(CS_BLOCK) void cs_eval_clauses(cs_tables T, const c
       b.lo += rec.w;
       b.hi += rec.w;
       v = cs_ev_not(cs_ev_eq(a, b));
+    } else if (rec.x == CS_CL_EQ || rec.x == CS_CL_LT) {
+      v = rec.x == CS_CL_EQ ? cs_ev_eq_shifted(dom[rec.y], dom[rec.z], rec.w) : cs_ev_lt_shifted(dom[rec.y], dom[rec.z], rec.w);
+    } else if (rec.x == CS_CL_OR2) {
+      cs_val t[2];
+      for (int k = 0; k < 2; k++) {
+        const int4 l = T.lit[rec.y + k];
+        t[k] = cs_ev_lt_shifted(dom[l.x], dom[l.y], l.z);
+      }
+      v = cs_ev_or(t[0], t[1]);
     } else if (rec.x == CS_CL_TREE) {
       cs_tree_scratch S;
       const int base = T.tree_off[rec.y], len = T.tree_off[rec.y + 1] - base;

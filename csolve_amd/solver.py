@@ -222,6 +222,12 @@ class Model:
         return res.status, res.props, out
 
 
+def set_linear_fast_paths(on: bool):
+    """Process-wide: whether models finalized from now on revise EQ / LT / two-literal OR clauses by direct
+    bound propagation (default) or through the expression-tree interpreter (csgpu_set_linear_fast_paths)."""
+    load_library().csgpu_set_linear_fast_paths(1 if on else 0)
+
+
 class Search:
     """Device-resident tree search over a finalized model (csgpu_search_*): a LIFO pool of open
     states in HBM, expanded and propagated in batches.  One instance per GPU/rank."""

@@ -125,6 +125,11 @@ int csgpu_model_finalize(csgpu_model *m);
  * Automatic: csgpu_propagate_batch_fb uses 4 when the model qualifies, else 3;
  * csgpu_propagate_batch uses 2, else 1. */
 int csgpu_model_set_kernel(csgpu_model *m, int which);
+/* Process-wide switch for models finalized afterwards: 1 (default) = EQ / LT / two-literal OR clauses
+ * over `VAR` or `VAR + constant` operands are revised by direct bound propagation (schedule.txt-style
+ * models then need no expression-tree interpreter); 0 = they stay expression trees.  Same fixpoints
+ * either way (tests compare the two). */
+void csgpu_set_linear_fast_paths(int on);
 /* 1 if the finalized model can run kernel `which` (1..4), else 0 */
 int csgpu_model_qualifies(const csgpu_model *m, int which);
 /* which kernel csgpu_propagate_batch will launch: 1, 2 or 3 (see above) */

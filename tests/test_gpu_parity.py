@@ -326,3 +326,61 @@ def test_large_batches_agree_across_kernels(kind, size, count):
             sets[k] = f[ok]
     if len(sets) == 2:
         assert torch.equal(sets[3], sets[4])
+
+
+@pytest.mark.parametrize("name", ["ref_schedule", "schedule6_s1", "ref_wcet"])
+def test_linear_fast_paths_equal_the_tree_interpreter(name):
+    """EQ / LT / two-literal OR clauses on the direct bound-propagation paths against the same clauses
+    through the expression-tree interpreter: same verdicts and fixpoints on multi-level random batches;
+    the schedule models need no tree at all on the fast paths."""
+    from csolve_amd.solver import set_linear_fast_paths, solve_root
+    text = open(golden("problems", name + ".txt")).read()
+    try:
+        set_linear_fast_paths(False)
+        slow = solve_root(text)
+        set_linear_fast_paths(True)
+        fast = solve_root(text)
+    finally:
+        set_linear_fast_paths(True)
+    assert (slow.domains() == fast.domains()).all()
+    assert slow.device_info()["tree_clauses"] > fast.device_info()["tree_clauses"]
+    if name != "ref_wcet":
+        assert fast.device_info()["tree_clauses"] == 0
+    rng = np.random.default_rng(11)
+    states = fast.domains()[None].copy()
+    for level in range(6):
+        nodes = _random_nodes(rng, states, 1024)
+        d_states, d_nodes = torch.from_numpy(states).cuda(), torch.from_numpy(nodes).cuda()
+        of, rf = fast.propagate(d_states, d_nodes)
+        os_, rs = slow.propagate(d_states, d_nodes)
+        torch.cuda.synchronize()
+        ok = rs[:, 0] >= 0
+        assert torch.equal(rf[:, 0] >= 0, ok)
+        assert torch.equal(of[ok], os_[ok])
+        assert torch.equal(rf[ok][:, 0], rs[ok][:, 0])
+        # the three-valued root value of every state, open or complete
+        assert torch.equal(fast.eval_root(of[ok].contiguous()), slow.eval_root(of[ok].contiguous()))
+        states = of[ok][:256].cpu().numpy()
+        if len(states) == 0:
+            break
+    # dives that assign the UPPER bound of every open variable in turn (an unbounded-above objective ends up at
+    # 2^31 - 2, where a shifted bound must not turn into a sentinel): same states, same root values
+    cur = fast.domains()[None].copy()
+    for step in range(fast.n_vars + 1):
+        open_vars = np.nonzero(cur[0, :, 0] < cur[0, :, 1])[0]
+        d_cur = torch.from_numpy(cur).cuda()
+        assert torch.equal(fast.eval_root(d_cur), slow.eval_root(d_cur))
+        if len(open_vars) == 0:
+            assert int(fast.eval_root(d_cur)[0]) in (0, 1)
+            break
+        v = int(open_vars[0])
+        node = torch.tensor([[v, cur[0, v, 1], cur[0, v, 1], 0]], dtype=torch.int32, device="cuda")
+        of, rf = fast.propagate(d_cur, node)
+        os_, rs = slow.propagate(d_cur, node)
+        torch.cuda.synchronize()
+        assert int(rf[0, 0] >= 0) == int(rs[0, 0] >= 0)
+        if int(rs[0, 0]) < 0:
+            cur[0, v, 1] -= 1  # the upper bound is inconsistent: shave it like the search would
+            continue
+        assert torch.equal(of, os_)
+        cur = of.cpu().numpy()

@@ -123,8 +123,12 @@ def test_device_tables_classification():
     assert q["max_list"] == 189 and q["lds_bytes_per_node"] == 64 * 8 + 16
     s = Model.from_dump(golden("models", "ref_sudoku.model")).build_tables().device_info()
     assert s["ne_clauses"] + s["skipped_clauses"] == 1158 and s["adjacency_entries"] == 1256 and s["max_list"] == 24
+    # wcet: 6 of the 15 clauses are `x = y` / `not (x < y)` over two variables (linear fast paths), the sums stay trees
     w = Model.from_dump(golden("models", "ref_wcet.model")).build_tables().device_info()
-    assert w["ne_clauses"] == 0 and w["tree_clauses"] == 15 and w["max_tree"] == 53
+    assert w["ne_clauses"] == 0 and w["tree_clauses"] == 9 and w["max_tree"] == 53
+    # schedule: definitions, precedences and disjunctive pairs all take the linear fast paths
+    sch = Model.from_dump(golden("models", "schedule6_s1.model")).build_tables().device_info()
+    assert sch["tree_clauses"] == 0 and sch["adjacency_entries"] > 0
 
 
 def test_generators_are_deterministic_and_reference_shaped():

@@ -369,7 +369,22 @@ __global__ __launch_bounds__(CS_BLOCK) void cs_propagate_events(cs_tables T, con
   for (long long node = (long long)blockIdx.x * CS_WAVES_PER_BLOCK + wave_in_block; node < batch; node += waves_total) {
     const cs_node_in nin = nodes[node];
     const cs_val *src = states_in + (size_t)nin.parent * n;
-    for (int v = lane; v < n; v += CS_WAVE) dom[v] = src[v];
+    /* larger states: eight strides of loads in flight at a time (a plain copy loop waits for every stride) */
+    if (n <= 2 * CS_WAVE) {
+      for (int v = lane; v < n; v += CS_WAVE) dom[v] = src[v];
+    } else for (int v0 = 0; v0 < n; v0 += 8 * CS_WAVE) {
+      cs_val t[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const int v = v0 + q * CS_WAVE + lane;
+        t[q] = v < n ? src[v] : cs_value(0);
+      }
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const int v = v0 + q * CS_WAVE + lane;
+        if (v < n) dom[v] = t[q];
+      }
+    }
     for (int w = lane; w < nw; w += CS_WAVE) { mask_a[w] = 0u; mask_b[w] = 0u; }
     cs_wave_sync();
 
@@ -793,11 +808,37 @@ __global__ __launch_bounds__(1024, (FW <= 1 && R <= 1 ? 8 : 4)) void cs_propagat
           }
         }
       } else {
+        /* large states: eight strides of loads in flight at a time (a plain copy loop waits for every
+         * stride before it issues the next one) */
         const cs_val *src = states_in + prow * n;
-        for (int v = lane; v < n; v += CS_WAVE) dom[v] = src[v];
+        for (int v0 = 0; v0 < n; v0 += 8 * CS_WAVE) {
+          cs_val t[8];
+#pragma unroll
+          for (int q = 0; q < 8; q++) {
+            const int v = v0 + q * CS_WAVE + lane;
+            t[q] = v < n ? src[v] : cs_value(0);
+          }
+#pragma unroll
+          for (int q = 0; q < 8; q++) {
+            const int v = v0 + q * CS_WAVE + lane;
+            if (v < n) dom[v] = t[q];
+          }
+        }
         if (forb_in != nullptr) {
           const u64 *fsrc = forb_in + prow * n * FW;
-          for (int k = lane; k < n * FW; k += CS_WAVE) forb[k] = fsrc[k];
+          for (int k0 = 0; k0 < n * FW; k0 += 8 * CS_WAVE) {
+            u64 t[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+              const int k = k0 + q * CS_WAVE + lane;
+              t[q] = k < n * FW ? fsrc[k] : 0ull;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+              const int k = k0 + q * CS_WAVE + lane;
+              if (k < n * FW) forb[k] = t[q];
+            }
+          }
         } else {
           for (int k = lane; k < n * FW; k += CS_WAVE) forb[k] = 0ull;
         }

@@ -11,6 +11,7 @@
 
 #include "../../include/csolve_gpu.h"
 #include "cs_kernels.hip.h"
+#include "cs_internal.h"
 
 static thread_local char g_err[512] = "";
 
@@ -638,13 +639,29 @@ extern "C" int csgpu_model_forbidden_words(const csgpu_model *m) { return m && m
 extern "C" int csgpu_propagate_batch_fb(const csgpu_model *m, const csgpu_val *d_states_in, const uint64_t *d_forb_in,
                                         const csgpu_node *d_nodes, csgpu_val *d_states_out, uint64_t *d_forb_out,
                                         csgpu_result *d_results, int64_t batch, void *stream) {
+  return csgpu_internal_propagate_fb(m, d_states_in, d_forb_in, d_nodes, d_states_out, d_forb_out, d_results, batch, NULL,
+                                     stream);
+}
+
+/* batch = upper bound the launch is sized for; d_batch (nullable) = the real count, on the device */
+extern "C" int csgpu_internal_propagate_fb(const csgpu_model *m, const csgpu_val *d_states_in, const uint64_t *d_forb_in,
+                                           const csgpu_node *d_nodes, csgpu_val *d_states_out, uint64_t *d_forb_out,
+                                           csgpu_result *d_results, int64_t batch, const uint64_t *d_batch,
+                                           void *stream) {
   if (m == NULL || batch < 0) return set_err(CSGPU_E_ARG, "null argument");
   if (!m->finalized) return set_err(CSGPU_E_STATE, "model is not finalized");
   if (!m->fb_words) return set_err(CSGPU_E_LIMIT, "model does not qualify for the forbidden-set kernel");
   if (batch == 0) return CSGPU_OK;
   if (d_states_in == NULL || d_nodes == NULL || d_states_out == NULL || d_results == NULL)
     return set_err(CSGPU_E_ARG, "null argument");
-  const int64_t chunks = (batch + CS_CHUNK - 1) / CS_CHUNK;
+  /* nodes per wave at a time: CS_CHUNK for large batches (one coalesced record load per 16 nodes); a batch
+   * smaller than the machine is spread thinner so that it does not run 16 nodes deep on a few waves */
+  int csz = CS_CHUNK;
+  {
+    const int64_t machine_waves = (int64_t)m->n_cus * 32;
+    while (csz > 1 && (batch + csz - 1) / csz < machine_waves) csz >>= 1;
+  }
+  const int64_t chunks = (batch + csz - 1) / csz;
   if (m->dense_waves && m->kernel_choice != 3) {
     /* register-resident variant (the default when the model qualifies) */
     size_t wgs = (160u * 1024u) / m->dense_bytes;
@@ -658,7 +675,7 @@ extern "C" int csgpu_propagate_batch_fb(const csgpu_model *m, const csgpu_val *d
     const int *root_lo_d = m->d_root_lo, *sym_off = m->d_sym_off;
     long long nb_d = (long long)batch;
     void *args_d[] = { &n, &tab_d, &slots, &dmin_d, &root_lo_d, &sym_off, &d_states_in, &d_forb_in, &d_nodes,
-                       &d_states_out, &d_forb_out, &d_results, &nb_d };
+                       &d_states_out, &d_forb_out, &d_results, &nb_d, &d_batch, &csz };
     const int chunks_v = (n + CS_WAVE - 1) / CS_WAVE;
     const int lanes = (chunks_v <= 1 ? 1 : (chunks_v <= 2 ? 2 : 4)) * CS_WAVE;
     const int fast = n == lanes && d_forb_in != NULL && d_forb_out != NULL;
@@ -679,7 +696,7 @@ extern "C" int csgpu_propagate_batch_fb(const csgpu_model *m, const csgpu_val *d
   const int *root_lo = m->d_root_lo;
   long long nb = (long long)batch;
   void *args[] = { &tab, &packed, &n_adj, &obits, &dmin, &root_lo, &d_states_in, &d_forb_in, &d_nodes,
-                   &d_states_out, &d_forb_out, &d_results, &nb };
+                   &d_states_out, &d_forb_out, &d_results, &nb, &d_batch, &csz };
   HIP_TRY(hipLaunchKernel(ne_bitset_kernel(m->img->sym_width, m->fb_words, m->host->n_vars), dim3((unsigned)grid),
                           dim3((unsigned)(m->fb_waves * CS_WAVE)), args, m->fb_bytes, (hipStream_t)stream));
   return CSGPU_OK;
@@ -702,6 +719,12 @@ extern "C" int csgpu_propagate_batch(const csgpu_model *m, const csgpu_val *d_st
 extern "C" int csgpu_propagate_batch_obj(const csgpu_model *m, const csgpu_val *d_states_in, const csgpu_node *d_nodes,
                                          csgpu_val *d_states_out, csgpu_result *d_results, int64_t batch,
                                          int32_t obj_lo, int32_t obj_hi, void *stream) {
+  return csgpu_internal_propagate_obj(m, d_states_in, d_nodes, d_states_out, d_results, batch, NULL, obj_lo, obj_hi, stream);
+}
+
+extern "C" int csgpu_internal_propagate_obj(const csgpu_model *m, const csgpu_val *d_states_in, const csgpu_node *d_nodes,
+                                            csgpu_val *d_states_out, csgpu_result *d_results, int64_t batch,
+                                            const uint64_t *d_batch, int32_t obj_lo, int32_t obj_hi, void *stream) {
   if (m == NULL || batch < 0) return set_err(CSGPU_E_ARG, "null argument");
   if (!m->finalized) return set_err(CSGPU_E_STATE, "model is not finalized");
   if (batch == 0) return CSGPU_OK; /* an empty batch needs no buffers */
@@ -728,8 +751,9 @@ extern "C" int csgpu_propagate_batch_obj(const csgpu_model *m, const csgpu_val *
     tab.obj_hi = obj_hi;
   }
   if ((m->kernel_choice == 3 || m->kernel_choice == 4) && tab.obj_var < 0)
-    return csgpu_propagate_batch_fb(m, d_states_in, NULL, d_nodes, d_states_out, NULL, d_results, batch, stream);
-  if (csgpu_model_get_kernel(m) == 2 && tab.obj_var < 0) {
+    return csgpu_internal_propagate_fb(m, d_states_in, NULL, d_nodes, d_states_out, NULL, d_results, batch, d_batch, stream);
+  const unsigned long long *bdev = (const unsigned long long *)d_batch;
+  if (csgpu_model_get_kernel(m) == 2 && tab.obj_var < 0 && d_batch == NULL) {
     /* persistent workgroups: as many as stay resident (LDS- and wave-slot-limited) */
     size_t wg_per_cu = (160u * 1024u) / m->lds_bytes;
     if (wg_per_cu > (size_t)(32 / m->lds_waves)) wg_per_cu = (size_t)(32 / m->lds_waves);
@@ -749,10 +773,10 @@ extern "C" int csgpu_propagate_batch_obj(const csgpu_model *m, const csgpu_val *
   }
   if (m->has_tree_adj)
     hipLaunchKernelGGL(cs_propagate_events<true>, dim3((unsigned)blocks), dim3(CS_BLOCK), lds, s, tab, in, nodes, out,
-                       res, (long long)batch);
+                       res, (long long)batch, bdev);
   else
     hipLaunchKernelGGL(cs_propagate_events<false>, dim3((unsigned)blocks), dim3(CS_BLOCK), lds, s, tab, in, nodes, out,
-                       res, (long long)batch);
+                       res, (long long)batch, bdev);
   HIP_TRY(hipGetLastError());
   return CSGPU_OK;
 }

@@ -15,6 +15,15 @@ extern "C" {
 int csgpu_model_from_host(cs_model *host, int lists_final, int domains_are_root, csgpu_model **out);
 cs_model *csgpu_model_host(csgpu_model *m);
 
+/* the batched fixpoint launched for an upper bound `batch` with the real node count left in device memory
+ * (`d_batch`, nullable): the search engine's small iterations need no host round trip for the count */
+int csgpu_internal_propagate_fb(const csgpu_model *m, const csgpu_val *d_states_in, const uint64_t *d_forb_in,
+                                const csgpu_node *d_nodes, csgpu_val *d_states_out, uint64_t *d_forb_out,
+                                csgpu_result *d_results, int64_t batch, const uint64_t *d_batch, void *stream);
+int csgpu_internal_propagate_obj(const csgpu_model *m, const csgpu_val *d_states_in, const csgpu_node *d_nodes,
+                                 csgpu_val *d_states_out, csgpu_result *d_results, int64_t batch,
+                                 const uint64_t *d_batch, int32_t obj_lo, int32_t obj_hi, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -353,11 +353,14 @@ template <bool HAS_TREE>
 __global__ __launch_bounds__(CS_BLOCK) void cs_propagate_events(cs_tables T, const cs_val *__restrict__ states_in,
                                                                 const cs_node_in *__restrict__ nodes,
                                                                 cs_val *__restrict__ states_out,
-                                                                cs_node_out *__restrict__ results, long long batch) {
+                                                                cs_node_out *__restrict__ results, long long batch,
+                                                                const unsigned long long *__restrict__ batch_dev) {
   extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
   const int lane = threadIdx.x & (CS_WAVE - 1);
   const int wave_in_block = threadIdx.x >> 6;
   const int n = T.n_vars, nw = T.n_words;
+  /* the search engine launches for an upper bound and leaves the real count on the device */
+  if (batch_dev != nullptr && (long long)*batch_dev < batch) batch = (long long)*batch_dev;
   /* per-wave LDS slice: domains, then the two changed masks */
   const size_t slice = (size_t)n * sizeof(cs_val) + 2 * (size_t)nw * sizeof(unsigned);
   const size_t slice_al = (slice + 15) & ~(size_t)15;
@@ -714,13 +717,15 @@ __global__ __launch_bounds__(1024, (FW <= 1 && R <= 1 ? 8 : 4)) void cs_propagat
     cs_tables T, const E *__restrict__ adj_packed, int n_adj, int obits, int dmin, const int *__restrict__ root_lo,
     const cs_val *__restrict__ states_in, const unsigned long long *__restrict__ forb_in,
     const cs_node_in *__restrict__ nodes, cs_val *__restrict__ states_out, unsigned long long *__restrict__ forb_out,
-    cs_node_out *__restrict__ results, long long batch) {
+    cs_node_out *__restrict__ results, long long batch, const unsigned long long *__restrict__ batch_dev,
+    int csz /* nodes a wave takes at a time, 1..16: small for small batches, to spread them over the machine */) {
   extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
   typedef unsigned long long u64;
   const int lane = threadIdx.x & (CS_WAVE - 1);
   const int wave_in_block = threadIdx.x >> 6;
   const int waves_per_block = blockDim.x >> 6;
   const int n = T.n_vars, nw = T.n_words;
+  if (batch_dev != nullptr && (long long)*batch_dev < batch) batch = (long long)*batch_dev;
   /* LDS: {begin,end}[n] | root_lo[n] | packed adjacency | per wave: domains, sets, two masks, counter */
   int2 *s_off2 = (int2 *)cs_lds;
   const size_t off_bytes = (((size_t)n * sizeof(int2)) + 15) & ~(size_t)15;
@@ -746,11 +751,11 @@ __global__ __launch_bounds__(1024, (FW <= 1 && R <= 1 ? 8 : 4)) void cs_propagat
   __syncthreads();
 
   const unsigned omask = (1u << obits) - 1u;
-  const long long chunks = (batch + CS_CHUNK - 1) / CS_CHUNK;
+  const long long chunks = (batch + csz - 1) / csz;
   const long long waves_total = (long long)gridDim.x * waves_per_block;
   for (long long chunk = (long long)blockIdx.x * waves_per_block + wave_in_block; chunk < chunks; chunk += waves_total) {
-    const long long base = chunk * CS_CHUNK;
-    const int cnt = (int)(batch - base < CS_CHUNK ? batch - base : CS_CHUNK);
+    const long long base = chunk * csz;
+    const int cnt = (int)(batch - base < csz ? batch - base : csz);
     cs_node_in rec;
     rec.var = -1; rec.lo = 0; rec.hi = 0; rec.parent = 0;
     if (lane < cnt) rec = nodes[base + lane];
@@ -1015,9 +1020,11 @@ __global__ __launch_bounds__(1024, (FW * R <= 1 ? 8 : 4)) void cs_propagate_ne_r
     const int *__restrict__ sym_off, const cs_val *__restrict__ states_in,
     const unsigned long long *__restrict__ forb_in, const cs_node_in *__restrict__ nodes,
     cs_val *__restrict__ states_out, unsigned long long *__restrict__ forb_out, cs_node_out *__restrict__ results,
-    long long batch) {
+    long long batch, const unsigned long long *__restrict__ batch_dev,
+    int csz /* nodes a wave takes at a time, 1..16: small for small batches, to spread them over the machine */) {
   extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
   constexpr int W = CS_WAVE * R; /* columns of the table */
+  if (batch_dev != nullptr && (long long)*batch_dev < batch) batch = (long long)*batch_dev;
   constexpr int NW = 2 * FW;     /* 32-bit words of forbidden set per variable */
   const int lane = threadIdx.x & (CS_WAVE - 1);
   const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); /* keeps row addresses scalar */
@@ -1045,11 +1052,11 @@ __global__ __launch_bounds__(1024, (FW * R <= 1 ? 8 : 4)) void cs_propagate_ne_r
   const uint2 *forb_in2 = (const uint2 *)forb_in; /* one u64 = {low word, high word} */
   uint2 *forb_out2 = (uint2 *)forb_out;
 
-  const long long chunks = (batch + CS_CHUNK - 1) / CS_CHUNK;
+  const long long chunks = (batch + csz - 1) / csz;
   const long long waves_total = (long long)gridDim.x * waves_per_block;
   for (long long chunk = (long long)blockIdx.x * waves_per_block + wave_in_block; chunk < chunks; chunk += waves_total) {
-    const long long base = chunk * CS_CHUNK;
-    const int cnt = (int)(batch - base < CS_CHUNK ? batch - base : CS_CHUNK);
+    const long long base = chunk * csz;
+    const int cnt = (int)(batch - base < csz ? batch - base : csz);
     cs_node_in rec;
     rec.var = -1; rec.lo = 0; rec.hi = 0; rec.parent = 0;
     if (lane < cnt) rec = nodes[base + lane];

@@ -14,6 +14,7 @@
 #include "../../include/csolve_gpu.h"
 #include "cs_arith.h"
 #include "cs_frontend.h"
+#include "cs_internal.h"
 
 #define SB 256 /* threads per block of the bookkeeping kernels */
 
@@ -65,13 +66,9 @@ static int flush_accept_results(csgpu_search *s);
 
 /* one wave per parent: the open variable with the smallest interval (ties: lowest index), the
  * reference's "-o smallest-domain" idea (strategy.c:85-91) as a pure function of the state.
- * Intervals wider than SPLIT_WIDTH are halved (two children) instead of enumerated. */
-__global__ __launch_bounds__(SB) void cs_branch(const cs_val *__restrict__ pool, long long first_row, int parents,
-                                                int n, int *__restrict__ branch_var, int *__restrict__ child_count) {
-  const int lane = threadIdx.x & 63;
-  const int p = blockIdx.x * (SB / 64) + (threadIdx.x >> 6);
-  if (p >= parents) return;
-  const cs_val *row = pool + (size_t)(first_row + p) * n;
+ * Intervals wider than SPLIT_WIDTH are halved (two children) instead of enumerated.
+ * -> var (-1: no open variable) and the number of children, in every lane */
+__device__ __forceinline__ void cs_branch_wave(const cs_val *__restrict__ row, int n, int lane, int *var, int *count) {
   /* key = (width-1) * 2^32 + index, minimised over the wave */
   unsigned long long best = ~0ull;
   for (int v = lane; v < n; v += 64) {
@@ -86,15 +83,26 @@ __global__ __launch_bounds__(SB) void cs_branch(const cs_val *__restrict__ pool,
     const unsigned long long other = __shfl_xor(best, o);
     best = other < best ? other : best;
   }
+  if (best == ~0ull) {
+    *var = -1;
+    *count = 0;
+  } else {
+    const unsigned long long width = (best >> 32) + 1ull;
+    *var = (int)(best & 0xffffffffu);
+    *count = width > SPLIT_WIDTH ? 2 : (int)width;
+  }
+}
+
+__global__ __launch_bounds__(SB) void cs_branch(const cs_val *__restrict__ pool, long long first_row, int parents,
+                                                int n, int *__restrict__ branch_var, int *__restrict__ child_count) {
+  const int lane = threadIdx.x & 63;
+  const int p = blockIdx.x * (SB / 64) + (threadIdx.x >> 6);
+  if (p >= parents) return;
+  int var, count;
+  cs_branch_wave(pool + (size_t)(first_row + p) * n, n, lane, &var, &count);
   if (lane == 0) {
-    if (best == ~0ull) {
-      branch_var[p] = -1;
-      child_count[p] = 0;
-    } else {
-      const unsigned long long width = (best >> 32) + 1ull;
-      branch_var[p] = (int)(best & 0xffffffffu);
-      child_count[p] = width > SPLIT_WIDTH ? 2 : (int)width;
-    }
+    branch_var[p] = var;
+    child_count[p] = count;
   }
 }
 
@@ -201,17 +209,12 @@ __global__ __launch_bounds__(1024) void cs_scan_classes(const int *__restrict__ 
 }
 
 /* one wave per parent writes its children {var, value, value, parent_row} */
-__global__ __launch_bounds__(SB) void cs_emit(const cs_val *__restrict__ pool, long long first_row, int parents, int n,
-                                              const int *__restrict__ branch_var, const int *__restrict__ child_off,
-                                              csgpu_node *__restrict__ nodes, int low_values_last,
-                                              unsigned scramble) {
-  const int lane = threadIdx.x & 63;
-  const int p = blockIdx.x * (SB / 64) + (threadIdx.x >> 6);
-  if (p >= parents) return;
-  const int var = branch_var[p];
+/* one wave writes the children {var, value, value, parent_row} of one parent at nodes[beg, beg + cnt) */
+__device__ __forceinline__ void cs_emit_wave(const cs_val *__restrict__ pool, long long row, int n, int var, int beg, int cnt,
+                                             csgpu_node *__restrict__ nodes, int low_values_last, unsigned scramble,
+                                             int lane) {
   if (var < 0) return;
-  const cs_val d = pool[(size_t)(first_row + p) * n + var];
-  const int beg = child_off[p], cnt = child_off[p + 1] - beg;
+  const cs_val d = pool[(size_t)row * n + var];
   const long long width = (long long)d.hi - (long long)d.lo + 1;
   if (width > SPLIT_WIDTH) { /* two halves, lower half first */
     const int mid = (int)(((long long)d.lo + (long long)d.hi) >> 1);
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(SB) void cs_emit(const cs_val *__restrict__ pool, l
       nd.var = var;
       nd.lo = lower ? d.lo : mid + 1;
       nd.hi = lower ? mid : d.hi;
-      nd.parent = (int)(first_row + p);
+      nd.parent = (int)row;
       nodes[beg + lane] = nd;
     }
     return;
@@ -234,17 +237,57 @@ __global__ __launch_bounds__(SB) void cs_emit(const cs_val *__restrict__ pool, l
       /* ANY: the values are tried from a pseudo-random starting point (the reference randomises its
        * value order too: the seed of step_val, csolve.c:284,331-338).  Deterministic: a function of
        * the variable, the row and the iteration only. */
-      unsigned h = (scramble ^ (unsigned)var * 2654435761u ^ (unsigned)(first_row + p) * 40503u);
+      unsigned h = (scramble ^ (unsigned)var * 2654435761u ^ (unsigned)row * 40503u);
       h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
       value = d.lo + (int)(((unsigned)k + h) % (unsigned)cnt);
     }
     nd.var = var;
     nd.lo = value;
     nd.hi = value;
-    nd.parent = (int)(first_row + p);
+    nd.parent = (int)row;
     nodes[beg + k] = nd;
   }
 }
+
+__global__ __launch_bounds__(SB) void cs_emit(const cs_val *__restrict__ pool, long long first_row, int parents, int n,
+                                              const int *__restrict__ branch_var, const int *__restrict__ child_off,
+                                              csgpu_node *__restrict__ nodes, int low_values_last,
+                                              unsigned scramble) {
+  const int lane = threadIdx.x & 63;
+  const int p = blockIdx.x * (SB / 64) + (threadIdx.x >> 6);
+  if (p >= parents) return;
+  cs_emit_wave(pool, first_row + p, n, branch_var[p], child_off[p], child_off[p + 1] - child_off[p], nodes,
+               low_values_last, scramble, lane);
+}
+
+/* ---- small iterations (at most SMALL_PARENTS parents: always for ANY / MIN / MAX): one workgroup does what
+ * cs_branch + cs_scan + cs_emit do, and leaves the number of children on the device, so that the host need not
+ * read anything before it launches the fixpoint ---- */
+#define SMALL_PARENTS 256
+__global__ __launch_bounds__(1024) void cs_expand_small(const cs_val *__restrict__ pool, long long first_row, int parents,
+                                                        int n, csgpu_node *__restrict__ nodes,
+                                                        unsigned long long *__restrict__ counters, int low_values_last,
+                                                        unsigned scramble) {
+  __shared__ int s_var[SMALL_PARENTS], s_cnt[SMALL_PARENTS], s_off[SMALL_PARENTS];
+  __shared__ long long s_part[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x < C_PER_ITERATION) counters[threadIdx.x] = 0ull;
+  for (int p = wave; p < parents; p += 16) {
+    int var, count;
+    cs_branch_wave(pool + (size_t)(first_row + p) * n, n, lane, &var, &count);
+    if (lane == 0) { s_var[p] = var; s_cnt[p] = count; }
+  }
+  __syncthreads();
+  long long total;
+  const int t = (int)threadIdx.x;
+  const long long ex = cs_block_excl_scan(t < parents ? (long long)s_cnt[t] : 0, s_part, &total);
+  if (t < parents) s_off[t] = (int)ex;
+  if (t == 0) counters[C_TOTAL_CHILDREN] = (unsigned long long)total;
+  __syncthreads();
+  for (int p = wave; p < parents; p += 16)
+    cs_emit_wave(pool, first_row + p, n, s_var[p], s_off[p], s_cnt[p], nodes, low_values_last, scramble, lane);
+}
+
 
 /* Classification of the children, deterministic: pool rows and the order of the solution check
  * depend on the child index only (block counts -> exclusive scan -> rows), never on which
@@ -305,13 +348,55 @@ __global__ __launch_bounds__(SB) void cs_classify_assign(const csgpu_result *__r
   }
 }
 
+/* small iterations: cs_classify_count + cs_scan_classes + cs_classify_assign in one workgroup, the number of
+ * children read from the device.  Same rows and the same order as the large path (tiles in child order). */
+__global__ __launch_bounds__(1024) void cs_classify_small(const csgpu_result *__restrict__ res, long long new_top,
+                                                          int *__restrict__ dest, int *__restrict__ complete_list,
+                                                          unsigned long long *__restrict__ counters) {
+  __shared__ long long s_part[16];
+  const int children = (int)counters[C_TOTAL_CHILDREN];
+  long long carry = 0; /* survivors in the low half, complete children in the high half: one scan for both */
+  long long cuts = 0, props = 0, revs = 0; /* per thread, reduced once at the end */
+  for (int base = 0; base < children; base += 1024) {
+    const int i = base + (int)threadIdx.x;
+    int status = -2;
+    if (i < children) {
+      status = res[i].status;
+      props += res[i].props;
+      revs += res[i].revisions;
+      cuts += status == -1;
+    }
+    long long total;
+    const long long x = (long long)(status > 0) | ((long long)(status == 0) << 32);
+    const long long ex = carry + cs_block_excl_scan(x, s_part, &total);
+    if (i < children) {
+      dest[i] = status > 0 ? (int)(new_top + (ex & 0xffffffffll)) : -1;
+      if (status == 0) complete_list[ex >> 32] = i;
+    }
+    carry += total;
+  }
+  long long t_cuts, t_props, t_revs;
+  (void)cs_block_excl_scan(cuts, s_part, &t_cuts);
+  (void)cs_block_excl_scan(props, s_part, &t_props);
+  (void)cs_block_excl_scan(revs, s_part, &t_revs);
+  if (threadIdx.x == 0) {
+    counters[C_SURVIVORS] = (unsigned long long)(carry & 0xffffffffll);
+    counters[C_COMPLETE] = (unsigned long long)(carry >> 32);
+    counters[C_CUTS] = (unsigned long long)t_cuts;
+    counters[C_PROPS] = (unsigned long long)t_props;
+    counters[C_REVS] = (unsigned long long)t_revs;
+  }
+}
+
 /* one wave per child: copy survivors into their pool rows */
 __global__ __launch_bounds__(SB) void cs_scatter(const cs_val *__restrict__ child_states, const int *__restrict__ dest,
                                                  int children, int n, cs_val *__restrict__ pool,
                                                  const unsigned long long *__restrict__ child_forb,
-                                                 unsigned long long *__restrict__ pool_forb, int fw) {
+                                                 unsigned long long *__restrict__ pool_forb, int fw,
+                                                 const unsigned long long *__restrict__ children_dev) {
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * (SB / 64) + (threadIdx.x >> 6);
+  if (children_dev != nullptr && (unsigned long long)children > *children_dev) children = (int)*children_dev;
   if (i >= children) return;
   const int d = dest[i];
   if (d < 0) return;
@@ -672,51 +757,80 @@ static int one_iteration(csgpu_search *s) {
   }
   const long long first_row = s->top - parents;
   if (parents == 0) return CSGPU_OK;
-  HIP_OK(hipMemsetAsync(s->d_counters, 0, sizeof(unsigned long long) * C_PER_ITERATION, 0));
-  const unsigned pb = (unsigned)((parents + 3) / 4);
-  hipLaunchKernelGGL(cs_branch, dim3(pb), dim3(SB), 0, 0, s->pool, first_row, (int)parents, n, s->d_branch_var,
-                     s->d_child_count);
-  hipLaunchKernelGGL(cs_scan, dim3(1), dim3(1024), 0, 0, s->d_child_count, (int)parents, s->d_child_off, s->d_counters,
-                     (int)C_TOTAL_CHILDREN);
-  /* first host read of the iteration: the number of children, and with it what the previous
-   * iteration's accept left behind (solutions so far, incumbent) */
-  unsigned long long head[C_COUNT - C_TOTAL_CHILDREN];
-  HIP_OK(hipMemcpy(head, s->d_counters + C_TOTAL_CHILDREN, sizeof head, hipMemcpyDeviceToHost));
-  const int64_t children = (int64_t)head[0];
-  int rc0 = apply_accept_results(s, head[C_SOLUTIONS - C_TOTAL_CHILDREN], (int)(unsigned)head[C_BEST - C_TOTAL_CHILDREN]);
-  if (rc0 != CSGPU_OK) return rc0;
-  if (children > s->max_children) return fail(CSGPU_E_LIMIT, "internal: more children than the batch buffers hold");
-  hipLaunchKernelGGL(cs_emit, dim3(pb), dim3(SB), 0, 0, s->pool, first_row, (int)parents, n, s->d_branch_var,
-                     s->d_child_off, s->d_nodes, s->objective == CS_OBJ_MAX ? 0 : 1,
-                     s->objective == CS_OBJ_ANY ? (unsigned)(s->st.iterations * 2654435761ull + 0x9e3779b9u) | 1u : 0u);
-  s->top -= parents;
-  s->st.iterations++;
-  if (children == 0) return CSGPU_OK;
-
+  const int small = parents <= SMALL_PARENTS;
+  const int low_last = s->objective == CS_OBJ_MAX ? 0 : 1;
+  const unsigned scramble =
+      s->objective == CS_OBJ_ANY ? (unsigned)(s->st.iterations * 2654435761ull + 0x9e3779b9u) | 1u : 0u;
   /* the incumbent tightens "<obj>" for every child (objective.c:101-126) */
   int32_t obj_lo = CS_DOM_MIN, obj_hi = CS_DOM_MAX;
   if (s->objective == CS_OBJ_MIN) obj_hi = cs_add(s->st.best, cs_neg(1));
   if (s->objective == CS_OBJ_MAX) obj_lo = cs_add(s->st.best, 1);
+  int64_t children;          /* what the launches are sized for */
+  const uint64_t *d_children; /* where the real count is, when the host does not know it yet */
+  if (small) {
+    /* one workgroup expands; nothing is read back before the fixpoint is launched */
+    hipLaunchKernelGGL(cs_expand_small, dim3(1), dim3(1024), 0, 0, s->pool, first_row, (int)parents, n, s->d_nodes,
+                       s->d_counters, low_last, scramble);
+    children = parents * s->max_width;
+    d_children = (const uint64_t *)(s->d_counters + C_TOTAL_CHILDREN);
+  } else {
+    HIP_OK(hipMemsetAsync(s->d_counters, 0, sizeof(unsigned long long) * C_PER_ITERATION, 0));
+    const unsigned pb = (unsigned)((parents + 3) / 4);
+    hipLaunchKernelGGL(cs_branch, dim3(pb), dim3(SB), 0, 0, s->pool, first_row, (int)parents, n, s->d_branch_var,
+                       s->d_child_count);
+    hipLaunchKernelGGL(cs_scan, dim3(1), dim3(1024), 0, 0, s->d_child_count, (int)parents, s->d_child_off, s->d_counters,
+                       (int)C_TOTAL_CHILDREN);
+    /* first host read of the iteration: the number of children, and with it what the previous
+     * iteration's accept left behind (solutions so far, incumbent) */
+    unsigned long long head[C_COUNT - C_TOTAL_CHILDREN];
+    HIP_OK(hipMemcpy(head, s->d_counters + C_TOTAL_CHILDREN, sizeof head, hipMemcpyDeviceToHost));
+    children = (int64_t)head[0];
+    d_children = NULL;
+    int rc0 = apply_accept_results(s, head[C_SOLUTIONS - C_TOTAL_CHILDREN], (int)(unsigned)head[C_BEST - C_TOTAL_CHILDREN]);
+    if (rc0 != CSGPU_OK) return rc0;
+    if (children > s->max_children) return fail(CSGPU_E_LIMIT, "internal: more children than the batch buffers hold");
+    hipLaunchKernelGGL(cs_emit, dim3(pb), dim3(SB), 0, 0, s->pool, first_row, (int)parents, n, s->d_branch_var,
+                       s->d_child_off, s->d_nodes, low_last, scramble);
+    /* the incumbent may just have improved */
+    if (s->objective == CS_OBJ_MIN) obj_hi = cs_add(s->st.best, cs_neg(1));
+    if (s->objective == CS_OBJ_MAX) obj_lo = cs_add(s->st.best, 1);
+  }
+  s->top -= parents;
+  s->st.iterations++;
+  if (children == 0) return CSGPU_OK;
+
   int rc;
   if (s->fw > 0)
-    rc = csgpu_propagate_batch_fb(s->m, (const csgpu_val *)s->pool, (const uint64_t *)s->pool_forb, s->d_nodes,
-                                  (csgpu_val *)s->d_child_states, (uint64_t *)s->d_child_forb, s->d_results, children,
-                                  NULL);
+    rc = csgpu_internal_propagate_fb(s->m, (const csgpu_val *)s->pool, (const uint64_t *)s->pool_forb, s->d_nodes,
+                                     (csgpu_val *)s->d_child_states, (uint64_t *)s->d_child_forb, s->d_results, children,
+                                     d_children, NULL);
   else
-    rc = csgpu_propagate_batch_obj(s->m, (const csgpu_val *)s->pool, s->d_nodes, (csgpu_val *)s->d_child_states,
-                                   s->d_results, children, obj_lo, obj_hi, NULL);
+    rc = csgpu_internal_propagate_obj(s->m, (const csgpu_val *)s->pool, s->d_nodes, (csgpu_val *)s->d_child_states,
+                                      s->d_results, children, d_children, obj_lo, obj_hi, NULL);
   if (rc != CSGPU_OK) return rc;
   const unsigned cb = (unsigned)((children + SB - 1) / SB), cw = (unsigned)((children + 3) / 4);
-  hipLaunchKernelGGL(cs_classify_count, dim3(cb), dim3(SB), 0, 0, s->d_results, (int)children, s->d_block_surv,
-                     s->d_block_comp, s->d_block_cuts, s->d_block_props, s->d_block_revs);
-  hipLaunchKernelGGL(cs_scan_classes, dim3(1), dim3(1024), 0, 0, s->d_block_surv, s->d_block_comp, s->d_block_cuts,
-                     s->d_block_props, s->d_block_revs, (int)cb, s->d_surv_off, s->d_comp_off, s->d_counters);
-  hipLaunchKernelGGL(cs_classify_assign, dim3(cb), dim3(SB), 0, 0, s->d_results, (int)children, (long long)s->top,
-                     s->d_surv_off, s->d_comp_off, s->d_dest, s->d_complete_list);
+  if (small) {
+    hipLaunchKernelGGL(cs_classify_small, dim3(1), dim3(1024), 0, 0, s->d_results, (long long)s->top, s->d_dest,
+                       s->d_complete_list, s->d_counters);
+  } else {
+    hipLaunchKernelGGL(cs_classify_count, dim3(cb), dim3(SB), 0, 0, s->d_results, (int)children, s->d_block_surv,
+                       s->d_block_comp, s->d_block_cuts, s->d_block_props, s->d_block_revs);
+    hipLaunchKernelGGL(cs_scan_classes, dim3(1), dim3(1024), 0, 0, s->d_block_surv, s->d_block_comp, s->d_block_cuts,
+                       s->d_block_props, s->d_block_revs, (int)cb, s->d_surv_off, s->d_comp_off, s->d_counters);
+    hipLaunchKernelGGL(cs_classify_assign, dim3(cb), dim3(SB), 0, 0, s->d_results, (int)children, (long long)s->top,
+                       s->d_surv_off, s->d_comp_off, s->d_dest, s->d_complete_list);
+  }
   hipLaunchKernelGGL(cs_scatter, dim3(cw), dim3(SB), 0, 0, s->d_child_states, s->d_dest, (int)children, n, s->pool,
-                     s->d_child_forb, s->pool_forb, s->fw);
-  unsigned long long c[C_PER_ITERATION];
+                     s->d_child_forb, s->pool_forb, s->fw, (const unsigned long long *)d_children);
+  /* the (only, for a small iteration) host read: class counts, the real number of children, and what the
+   * previous iteration's accept left behind */
+  unsigned long long c[C_COUNT];
   HIP_OK(hipMemcpy(c, s->d_counters, sizeof c, hipMemcpyDeviceToHost));
+  if (small) {
+    children = (int64_t)c[C_TOTAL_CHILDREN];
+    rc = apply_accept_results(s, c[C_SOLUTIONS], (int)(unsigned)c[C_BEST]);
+    if (rc != CSGPU_OK) return rc;
+  }
   s->top += (int64_t)c[C_SURVIVORS];
   if (s->top > s->peak) s->peak = s->top;
   s->st.nodes += (uint64_t)children;

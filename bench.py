@@ -253,8 +253,8 @@ def search_workload(args, rank, world, local, dist):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--queens", type=int, default=64)
     ap.add_argument("--schedule", type=int, default=0, help="tasks of a schedule.txt-style optimisation model (tree clauses, "
                     "general kernel) instead of queens (BASELINE configs[4] shape)")

@@ -155,3 +155,33 @@ def test_reset_runs_the_same_search_again():
         s.put(model.root_state())
         runs.append(s.run())
     assert runs[0]["solutions"] == 352 and runs[0] == runs[1]
+
+
+def test_two_engines_share_the_incumbent():
+    """Two engines on halves of a MIN search that tell each other their incumbents after every slice
+    (what ShardedSearch does across ranks; set_best must not lose an incumbent the engine has found but
+    not yet reported): same optimum as one engine, fewer nodes than two independent halves."""
+    from csolve_amd import problems
+    from csolve_amd.solver import Search, solve_root
+    model = solve_root(problems.schedule(8, 1))
+    one = Search(model, 1 << 18, 1 << 14)
+    one.put(model.root_state())
+    ref = one.run()
+    assert ref["done"] and ref["best"] == 31
+    a, b = Search(model, 1 << 18, 1 << 14), Search(model, 1 << 18, 1 << 14)
+    a.put(model.root_state())
+    st = a.run(6)
+    assert not st["done"] and st["pool"] >= 2
+    b.put(a.take(st["pool"] // 2).contiguous())
+    sa = sb = None
+    for _ in range(100000):
+        sa, sb = a.run(8), b.run(8)
+        best = min(sa["best"], sb["best"])
+        a.set_best(best)
+        b.set_best(best)
+        if sa["done"] and sb["done"]:
+            break
+    assert sa["done"] and sb["done"]
+    assert min(sa["best"], sb["best"]) == 31
+    row = a.best_solution() if sa["best"] == 31 and a.best_solution() is not None else b.best_solution()
+    assert row is not None and row[model.objective_var] == 31

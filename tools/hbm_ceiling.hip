@@ -9,6 +9,35 @@
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
+template <typename T, int ROWS_PER_WAVE_ITER, int NT>
+__global__ __launch_bounds__(512) void stream2nt(const T *__restrict__ a, const T *__restrict__ b, T *__restrict__ c,
+                                                 T *__restrict__ d, long long rows, int row_elems) {
+  const int lane = threadIdx.x & 63;
+  const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const long long waves = (long long)gridDim.x * (blockDim.x >> 6);
+  for (long long r = wave * ROWS_PER_WAVE_ITER; r < rows; r += waves * ROWS_PER_WAVE_ITER) {
+    T x[ROWS_PER_WAVE_ITER], y[ROWS_PER_WAVE_ITER];
+#pragma unroll
+    for (int k = 0; k < ROWS_PER_WAVE_ITER; k++) {
+      const long long rr = r + k < rows ? r + k : rows - 1;
+      x[k] = (NT & 1) ? __builtin_nontemporal_load(&a[rr * row_elems + lane]) : a[rr * row_elems + lane];
+      y[k] = (NT & 1) ? __builtin_nontemporal_load(&b[rr * row_elems + lane]) : b[rr * row_elems + lane];
+    }
+#pragma unroll
+    for (int k = 0; k < ROWS_PER_WAVE_ITER; k++) {
+      if (r + k < rows) {
+        if (NT & 2) {
+          __builtin_nontemporal_store(x[k], &c[(r + k) * row_elems + lane]);
+          __builtin_nontemporal_store(y[k], &d[(r + k) * row_elems + lane]);
+        } else {
+          c[(r + k) * row_elems + lane] = x[k];
+          d[(r + k) * row_elems + lane] = y[k];
+        }
+      }
+    }
+  }
+}
+
 template <typename T, int ROWS_PER_WAVE_ITER>
 __global__ __launch_bounds__(512) void stream2(const T *__restrict__ a, const T *__restrict__ b, T *__restrict__ c,
                                                T *__restrict__ d, long long rows, int row_elems) {
@@ -79,6 +108,15 @@ int main(int argc, char **argv) {
     const int grid = (int)((rows + 7) / 8);
     printf("one row per wave, grid %d x 512, 8 B/lane:", grid);
     float ms = time_ms([&] { hipLaunchKernelGGL((stream2<unsigned long long, 1>), dim3(grid), dim3(512), 0, 0, (const unsigned long long *)a, (const unsigned long long *)b, (unsigned long long *)c, (unsigned long long *)d, rows, 64); }, 20);
+    printf("  -> %.0f GB/s\n", total / ms / 1e6);
+  }
+  for (int nt = 1; nt <= 3; nt++) {
+    const int grid = cus * 2;
+    printf("persistent grid %5d x 512, 2 rows/iter, nontemporal %s%s:", grid, (nt & 1) ? "loads " : "", (nt & 2) ? "stores" : "");
+    float ms = 0;
+    if (nt == 1) ms = time_ms([&] { hipLaunchKernelGGL((stream2nt<unsigned long long, 2, 1>), dim3(grid), dim3(512), 0, 0, (const unsigned long long *)a, (const unsigned long long *)b, (unsigned long long *)c, (unsigned long long *)d, rows, 64); }, 20);
+    if (nt == 2) ms = time_ms([&] { hipLaunchKernelGGL((stream2nt<unsigned long long, 2, 2>), dim3(grid), dim3(512), 0, 0, (const unsigned long long *)a, (const unsigned long long *)b, (unsigned long long *)c, (unsigned long long *)d, rows, 64); }, 20);
+    if (nt == 3) ms = time_ms([&] { hipLaunchKernelGGL((stream2nt<unsigned long long, 2, 3>), dim3(grid), dim3(512), 0, 0, (const unsigned long long *)a, (const unsigned long long *)b, (unsigned long long *)c, (unsigned long long *)d, rows, 64); }, 20);
     printf("  -> %.0f GB/s\n", total / ms / 1e6);
   }
   {

@@ -265,6 +265,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--kernel", type=int, default=0, help="0 best, 1 general, 2 LDS-resident, 3 forbidden sets in LDS, 4 forbidden sets in registers")
     ap.add_argument("--rebuild-sets", action="store_true", help="forbidden-set kernel without resident sets")
+    ap.add_argument("--layout", choices=["intervals", "sets"], default="intervals",
+                    help="intervals: {lo,hi} states with the forbidden sets next to them (default); sets: the states are "
+                         "the forbidden sets alone (csgpu_propagate_batch_sets, kernel 4 models), half the bytes per node")
     ap.add_argument("--workload", choices=["propagate", "search"], default="propagate")
     ap.add_argument("--search-queens", type=int, default=13)
     ap.add_argument("--search-objective", choices=["ALL", "ANY"], default="ALL")
@@ -326,9 +329,17 @@ def main():
     states_out = torch.empty((B, n, 2), dtype=torch.int32, device="cuda")
     results = torch.empty((B, 4), dtype=torch.int32, device="cuda")
     forb_out = torch.empty((B, n, fw), dtype=torch.int64, device="cuda") if use_sets else None
+    sets_only = args.layout == "sets"
+    if sets_only:
+        if not (use_sets and model.qualifies(4) and forced in (0, 4)):
+            raise SystemExit("--layout sets needs a model that qualifies for kernel 4 (and --kernel 0 or 4)")
+        sets_in = model.pack_sets(states_in)
+        torch.cuda.synchronize()
 
     def step():
-        if use_sets:
+        if sets_only:
+            model.propagate_sets(sets_in, nodes, sets_out=forb_out, results=results)
+        elif use_sets:
             model.propagate_fb(states_in, nodes, forb_in=forb_in, states_out=states_out, forb_out=forb_out,
                                results=results)
         else:
@@ -355,6 +366,8 @@ def main():
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
 
+    if sets_only:
+        states_out = model.unpack_sets(forb_out)  # for the check against the CPU reference below
     res_h = results.cpu().numpy().astype(np.int64)
     totals = torch.tensor([res_h[:, 1].sum(), res_h[:, 2].sum(), B, int((res_h[:, 0] < 0).sum())],
                           dtype=torch.float64, device="cuda")
@@ -368,7 +381,7 @@ def main():
     # (DESIGN.md 2/4): per node instance the state in and out (16 B x n), the forbidden sets in and
     # out when they are resident (16 B x n x FW), the 16-B node record and the 16-B result.
     # The clause tables are read once per workgroup from L2 and are not counted.
-    alg_bytes = (16 * n + (16 * n * fw if use_sets else 0) + 16 + 16) * B
+    alg_bytes = ((0 if sets_only else 16 * n) + (16 * n * fw if use_sets else 0) + 16 + 16) * B
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
     # SURVEY 8(d) also prices every clause revision as 32 B of memory traffic (+ 8 B per narrowing);
     # in this design those bytes are LDS traffic, so that figure is reported separately
@@ -390,11 +403,11 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"{problem_name}propagation-only fixpoint (BASELINE configs[{4 if args.schedule else (2 if args.sudoku else 1)}]), seeded random-walk "
                                f"node instances resident in HBM",
-                   "instances_per_gpu": B, "variables": n, "forbidden_sets_resident": bool(use_sets), "clauses": info["ne_clauses"] + info["tree_clauses"],
+                   "instances_per_gpu": B, "variables": n, "forbidden_sets_resident": bool(use_sets), "layout": args.layout, "clauses": info["ne_clauses"] + info["tree_clauses"],
                    "inconsistent_fraction": fails_all / nodes_all,
                    "props_per_node": props_all / nodes_all, "revisions_per_node": revs_all / nodes_all},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None if (args.sudoku or args.schedule) else measured_traffic(kernel_name, n_q, B),
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None if (args.sudoku or args.schedule or sets_only) else measured_traffic(kernel_name, n_q, B),
                      "kernel": kernel_name, "kernel_ms": kernel_ms,
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "bytes_per_node_instance": alg_bytes // B,

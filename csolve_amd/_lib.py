@@ -84,6 +84,9 @@ def load_library():
     L.csgpu_model_set_kernel.argtypes = [vp, C.c_int]
     L.csgpu_model_qualifies.argtypes = [vp, C.c_int]
     L.csgpu_set_linear_fast_paths.argtypes = [C.c_int]
+    L.csgpu_sets_pack.argtypes = [vp, vp, vp, i64, vp]
+    L.csgpu_sets_unpack.argtypes = [vp, vp, vp, i64, vp]
+    L.csgpu_propagate_batch_sets.argtypes = [vp, vp, vp, vp, vp, i64, vp]
     L.csgpu_set_linear_fast_paths.restype = None
     L.csgpu_model_get_kernel.argtypes = [vp]
     L.csgpu_propagate_batch.argtypes = [vp, vp, vp, vp, vp, i64, vp]

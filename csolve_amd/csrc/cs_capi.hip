@@ -407,12 +407,15 @@ static const void *ne_bitset_kernel(int width, int fw, int n_vars) {
 
 /* register-resident forbidden-set kernel: entry width, set words, variables per lane; the FAST
  * instantiation (n_vars a multiple of 64 that fills the lanes, both set buffers) keeps D nodes in flight */
-static const void *ne_regs_kernel(int width, int fw, int n_vars, int fast) {
+static const void *ne_regs_kernel(int width, int fw, int n_vars, int fast, int sets_only) {
   const int chunks = (n_vars + CS_WAVE - 1) / CS_WAVE;
   const int r = chunks <= 1 ? 1 : (chunks <= 2 ? 2 : 4);
 #define CS_PICK_D(E, F, RR)                                                                        \
-  return fast ? (const void *)cs_propagate_ne_regs<E, F, RR, 2, true>                               \
-              : (const void *)cs_propagate_ne_regs<E, F, RR, 1, false>;
+  if (sets_only)                                                                                   \
+    return fast ? (const void *)cs_propagate_ne_regs<E, F, RR, 2, true, true>                       \
+                : (const void *)cs_propagate_ne_regs<E, F, RR, 1, false, true>;                     \
+  return fast ? (const void *)cs_propagate_ne_regs<E, F, RR, 2, true, false>                        \
+              : (const void *)cs_propagate_ne_regs<E, F, RR, 1, false, false>;
 #define CS_PICK_R(E, F)                                                                            \
   switch (r) {                                                                                     \
   case 1: CS_PICK_D(E, F, 1)                                                                       \
@@ -588,8 +591,9 @@ extern "C" int csgpu_model_finalize(csgpu_model *m) {
           m->dense_waves = best_waves;
           m->dense_bytes = bytes;
           if ((rc = upload(m->img->dense_tab, bytes, (int **)&m->d_dense_tab))) return rc;
-          for (int fast = 0; fast <= 1; fast++)
-            if ((rc = lds_limit(bytes, ne_regs_kernel(m->img->dense_width, m->fb_words, h->n_vars, fast)))) return rc;
+          for (int variant = 0; variant < 4; variant++)
+            if ((rc = lds_limit(bytes, ne_regs_kernel(m->img->dense_width, m->fb_words, h->n_vars, variant & 1, variant >> 1))))
+              return rc;
         }
       }
     }
@@ -636,6 +640,36 @@ extern "C" int csgpu_model_qualifies(const csgpu_model *m, int which) {
 
 extern "C" int csgpu_model_forbidden_words(const csgpu_model *m) { return m && m->finalized ? m->fb_words : 0; }
 
+/* the register-resident forbidden-set kernel (kernel 4); sets_only: the states are the sets alone */
+static int launch_regs(const csgpu_model *m, const csgpu_val *d_states_in, const uint64_t *d_forb_in,
+                       const csgpu_node *d_nodes, csgpu_val *d_states_out, uint64_t *d_forb_out, csgpu_result *d_results,
+                       int64_t batch, const uint64_t *d_batch, int sets_only, int flags, void *stream) {
+  int csz = CS_CHUNK;
+  {
+    const int64_t machine_waves = (int64_t)m->n_cus * 32;
+    while (csz > 1 && (batch + csz - 1) / csz < machine_waves) csz >>= 1;
+  }
+  const int64_t chunks = (batch + csz - 1) / csz;
+  size_t wgs = (160u * 1024u) / m->dense_bytes;
+  if (wgs > (size_t)(32 / m->dense_waves)) wgs = (size_t)(32 / m->dense_waves);
+  int64_t g = (int64_t)m->n_cus * (int64_t)wgs;
+  const int64_t need_wg = (chunks + m->dense_waves - 1) / m->dense_waves;
+  g *= 2; /* twice the resident grid: the dispatcher backfills CUs whose waves finish early (measured +1.5 %) */
+  if (g > need_wg) g = need_wg;
+  int n = m->host->n_vars, slots = m->img->dense_slots, dmin_d = m->img->dense_dmin;
+  const void *tab_d = m->d_dense_tab;
+  const int *root_lo_d = m->d_root_lo, *sym_off = m->d_sym_off;
+  long long nb_d = (long long)batch;
+  void *args_d[] = { &n, &tab_d, &slots, &dmin_d, &root_lo_d, &sym_off, &d_states_in, &d_forb_in, &d_nodes,
+                     &d_states_out, &d_forb_out, &d_results, &nb_d, &d_batch, &csz, &flags };
+  const int chunks_v = (n + CS_WAVE - 1) / CS_WAVE;
+  const int lanes = (chunks_v <= 1 ? 1 : (chunks_v <= 2 ? 2 : 4)) * CS_WAVE;
+  const int fast = n == lanes && d_forb_in != NULL && d_forb_out != NULL && flags == 0;
+  HIP_TRY(hipLaunchKernel(ne_regs_kernel(m->img->dense_width, m->fb_words, n, fast, sets_only), dim3((unsigned)g),
+                          dim3((unsigned)(m->dense_waves * CS_WAVE)), args_d, m->dense_bytes, (hipStream_t)stream));
+  return CSGPU_OK;
+}
+
 extern "C" int csgpu_propagate_batch_fb(const csgpu_model *m, const csgpu_val *d_states_in, const uint64_t *d_forb_in,
                                         const csgpu_node *d_nodes, csgpu_val *d_states_out, uint64_t *d_forb_out,
                                         csgpu_result *d_results, int64_t batch, void *stream) {
@@ -662,27 +696,8 @@ extern "C" int csgpu_internal_propagate_fb(const csgpu_model *m, const csgpu_val
     while (csz > 1 && (batch + csz - 1) / csz < machine_waves) csz >>= 1;
   }
   const int64_t chunks = (batch + csz - 1) / csz;
-  if (m->dense_waves && m->kernel_choice != 3) {
-    /* register-resident variant (the default when the model qualifies) */
-    size_t wgs = (160u * 1024u) / m->dense_bytes;
-    if (wgs > (size_t)(32 / m->dense_waves)) wgs = (size_t)(32 / m->dense_waves);
-    int64_t g = (int64_t)m->n_cus * (int64_t)wgs;
-    const int64_t need_wg = (chunks + m->dense_waves - 1) / m->dense_waves;
-    g *= 2; /* twice the resident grid: the dispatcher backfills CUs whose waves finish early (measured +1.5 %) */
-    if (g > need_wg) g = need_wg;
-    int n = m->host->n_vars, slots = m->img->dense_slots, dmin_d = m->img->dense_dmin;
-    const void *tab_d = m->d_dense_tab;
-    const int *root_lo_d = m->d_root_lo, *sym_off = m->d_sym_off;
-    long long nb_d = (long long)batch;
-    void *args_d[] = { &n, &tab_d, &slots, &dmin_d, &root_lo_d, &sym_off, &d_states_in, &d_forb_in, &d_nodes,
-                       &d_states_out, &d_forb_out, &d_results, &nb_d, &d_batch, &csz };
-    const int chunks_v = (n + CS_WAVE - 1) / CS_WAVE;
-    const int lanes = (chunks_v <= 1 ? 1 : (chunks_v <= 2 ? 2 : 4)) * CS_WAVE;
-    const int fast = n == lanes && d_forb_in != NULL && d_forb_out != NULL;
-    HIP_TRY(hipLaunchKernel(ne_regs_kernel(m->img->dense_width, m->fb_words, n, fast), dim3((unsigned)g),
-                            dim3((unsigned)(m->dense_waves * CS_WAVE)), args_d, m->dense_bytes, (hipStream_t)stream));
-    return CSGPU_OK;
-  }
+  if (m->dense_waves && m->kernel_choice != 3)
+    return launch_regs(m, d_states_in, d_forb_in, d_nodes, d_states_out, d_forb_out, d_results, batch, d_batch, 0, 0, stream);
   size_t wg_per_cu = (160u * 1024u) / m->fb_bytes;
   if (wg_per_cu > (size_t)(32 / m->fb_waves)) wg_per_cu = (size_t)(32 / m->fb_waves);
   if (wg_per_cu < 1) wg_per_cu = 1;
@@ -700,6 +715,81 @@ extern "C" int csgpu_internal_propagate_fb(const csgpu_model *m, const csgpu_val
   HIP_TRY(hipLaunchKernel(ne_bitset_kernel(m->img->sym_width, m->fb_words, m->host->n_vars), dim3((unsigned)grid),
                           dim3((unsigned)(m->fb_waves * CS_WAVE)), args, m->fb_bytes, (hipStream_t)stream));
   return CSGPU_OK;
+}
+
+/* ---- sets-only states (include/csolve_gpu.h) ------------------------------------------------------------ */
+
+__global__ void cs_fill_identity_nodes(cs_node_in *nodes, long long count) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) {
+    cs_node_in nd;
+    nd.var = -1; nd.lo = 0; nd.hi = 0; nd.parent = (int)i;
+    nodes[i] = nd;
+  }
+}
+
+static int sets_ready(const csgpu_model *m) {
+  if (m == NULL) return set_err(CSGPU_E_ARG, "null argument");
+  if (!m->finalized) return set_err(CSGPU_E_STATE, "model is not finalized");
+  if (!m->dense_waves) return set_err(CSGPU_E_LIMIT, "model does not qualify for the register-resident forbidden-set kernel");
+  return CSGPU_OK;
+}
+
+extern "C" int csgpu_sets_pack(const csgpu_model *m, const csgpu_val *d_states, uint64_t *d_sets, int64_t count, void *stream) {
+  int rc = sets_ready(m);
+  if (rc != CSGPU_OK) return rc;
+  if (count < 0) return set_err(CSGPU_E_ARG, "bad argument");
+  if (count == 0) return CSGPU_OK;
+  if (d_states == NULL || d_sets == NULL) return set_err(CSGPU_E_ARG, "null argument");
+  if (count > 0x7fffffff) return set_err(CSGPU_E_LIMIT, "too many states");
+  cs_node_in *d_nodes = NULL;
+  cs_node_out *d_res = NULL;
+  HIP_TRY(hipMalloc((void **)&d_nodes, (size_t)count * sizeof(cs_node_in)));
+  if (hipMalloc((void **)&d_res, (size_t)count * sizeof(cs_node_out)) != hipSuccess) {
+    (void)hipFree(d_nodes);
+    return set_err(CSGPU_E_HIP, "out of device memory");
+  }
+  hipLaunchKernelGGL(cs_fill_identity_nodes, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_nodes, (long long)count);
+  /* rebuild mode (every valued variable pushes), the intervals folded into the sets on the way out */
+  rc = launch_regs(m, d_states, NULL, (const csgpu_node *)d_nodes, NULL, d_sets, (csgpu_result *)d_res, count, NULL, 0,
+                   CS_K4_OUT_RESTRICT, stream);
+  hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+  (void)hipFree(d_nodes);
+  (void)hipFree(d_res);
+  if (rc != CSGPU_OK) return rc;
+  if (e != hipSuccess) return set_err(CSGPU_E_HIP, "%s", hipGetErrorString(e));
+  return CSGPU_OK;
+}
+
+extern "C" int csgpu_sets_unpack(const csgpu_model *m, const uint64_t *d_sets, csgpu_val *d_states, int64_t count, void *stream) {
+  int rc = sets_ready(m);
+  if (rc != CSGPU_OK) return rc;
+  if (count < 0) return set_err(CSGPU_E_ARG, "bad argument");
+  if (count == 0) return CSGPU_OK;
+  if (d_states == NULL || d_sets == NULL) return set_err(CSGPU_E_ARG, "null argument");
+  const int n = m->host->n_vars;
+  int64_t blocks = (count * n + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  const unsigned long long *sets = (const unsigned long long *)d_sets;
+  cs_val *states = (cs_val *)d_states;
+  switch (m->fb_words) {
+  case 1: hipLaunchKernelGGL(cs_sets_unpack<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n, m->d_root_lo, sets, states, (long long)count); break;
+  case 2: hipLaunchKernelGGL(cs_sets_unpack<2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n, m->d_root_lo, sets, states, (long long)count); break;
+  default: hipLaunchKernelGGL(cs_sets_unpack<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n, m->d_root_lo, sets, states, (long long)count); break;
+  }
+  HIP_TRY(hipGetLastError());
+  return CSGPU_OK;
+}
+
+extern "C" int csgpu_propagate_batch_sets(const csgpu_model *m, const uint64_t *d_sets_in, const csgpu_node *d_nodes,
+                                          uint64_t *d_sets_out, csgpu_result *d_results, int64_t batch, void *stream) {
+  int rc = sets_ready(m);
+  if (rc != CSGPU_OK) return rc;
+  if (batch < 0) return set_err(CSGPU_E_ARG, "bad argument");
+  if (batch == 0) return CSGPU_OK;
+  if (d_sets_in == NULL || d_nodes == NULL || d_sets_out == NULL || d_results == NULL)
+    return set_err(CSGPU_E_ARG, "null argument");
+  return launch_regs(m, NULL, d_sets_in, d_nodes, NULL, d_sets_out, d_results, batch, NULL, 1, 0, stream);
 }
 
 extern "C" int csgpu_model_get_kernel(const csgpu_model *m) {

@@ -1014,14 +1014,48 @@ __device__ __forceinline__ int cs_wave_sum(int x) {
  * in a timing-dependent 1-15 % of the nodes of large batches; the same loop with 32-bit shifts, or with
  * the consumers of the shift moved a few instructions away, is exact (DESIGN.md 3.4 has the
  * experiments).  tools/validate_k4.py and the large-batch GPU test guard this kernel. */
-template <typename E, int FW, int R, int D, bool FAST>
+/* 32-bit words of a forbidden set, word q = values 32 q .. 32 q + 31 relative to the variable's root lower bound:
+ * lowest and highest allowed value within [from, to] (first > last: none) */
+template <int NW>
+__device__ __forceinline__ void cs_set_bounds(const unsigned *w, int from, int to, int *first_out, int *last_out) {
+  int first = 0x7fffffff, last = -1;
+#pragma unroll
+  for (int q = 0; q < NW; q++) {
+    const int f = from - 32 * q, t = to - 32 * q; /* the interval in this word's coordinates */
+    const unsigned mlo = f <= 0 ? ~0u : (f > 31 ? 0u : ~0u << (f & 31));
+    const unsigned mhi = t >= 31 ? ~0u : (t < 0 ? 0u : ~0u >> ((31 - t) & 31));
+    const unsigned a = ~w[q] & mlo & mhi;
+    const int lo_q = a != 0u ? 32 * q + __builtin_ctz(a) : 0x7fffffff;
+    const int hi_q = a != 0u ? 32 * q + 31 - __builtin_clz(a) : -1;
+    first = lo_q < first ? lo_q : first;
+    last = hi_q > last ? hi_q : last;
+  }
+  *first_out = first;
+  *last_out = last;
+}
+
+/* mark every value outside [from, to] (relative) as forbidden */
+template <int NW>
+__device__ __forceinline__ void cs_set_restrict(unsigned *w, int from, int to) {
+#pragma unroll
+  for (int q = 0; q < NW; q++) {
+    const int f = from - 32 * q, t = to - 32 * q;
+    const unsigned mlo = f <= 0 ? ~0u : (f > 31 ? 0u : ~0u << (f & 31));
+    const unsigned mhi = t >= 31 ? ~0u : (t < 0 ? 0u : ~0u >> ((31 - t) & 31));
+    w[q] |= ~(mlo & mhi);
+  }
+}
+#define CS_K4_OUT_RESTRICT 1
+
+template <typename E, int FW, int R, int D, bool FAST, bool SO>
 __global__ __launch_bounds__(1024, (FW * R <= 1 ? 8 : 4)) void cs_propagate_ne_regs(
     int n, const E *__restrict__ tab_g, int slots, int dmin, const int *__restrict__ root_lo,
     const int *__restrict__ sym_off, const cs_val *__restrict__ states_in,
     const unsigned long long *__restrict__ forb_in, const cs_node_in *__restrict__ nodes,
     cs_val *__restrict__ states_out, unsigned long long *__restrict__ forb_out, cs_node_out *__restrict__ results,
     long long batch, const unsigned long long *__restrict__ batch_dev,
-    int csz /* nodes a wave takes at a time, 1..16: small for small batches, to spread them over the machine */) {
+    int csz /* nodes a wave takes at a time, 1..16: small for small batches, to spread them over the machine */,
+    int flags /* CS_K4_OUT_RESTRICT: the stored sets also mark the values outside the stored interval */) {
   extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
   constexpr int W = CS_WAVE * R; /* columns of the table */
   if (batch_dev != nullptr && (long long)*batch_dev < batch) batch = (long long)*batch_dev;
@@ -1048,7 +1082,7 @@ __global__ __launch_bounds__(1024, (FW * R <= 1 ? 8 : 4)) void cs_propagate_ne_r
     b0[r] = live[r] ? root_lo[vcl[r]] : 0;
     deg[r] = live[r] ? sym_off[vcl[r] + 1] - sym_off[vcl[r]] : 0;
   }
-  const bool have_in = FAST || forb_in != nullptr;
+  const bool have_in = FAST || SO || forb_in != nullptr;
   const uint2 *forb_in2 = (const uint2 *)forb_in; /* one u64 = {low word, high word} */
   uint2 *forb_out2 = (uint2 *)forb_out;
 
@@ -1070,7 +1104,7 @@ __global__ __launch_bounds__(1024, (FW * R <= 1 ? 8 : 4)) void cs_propagate_ne_r
     for (int d = 0; d < D; d++) {
       const size_t prow = (size_t)__builtin_amdgcn_readlane(rec.parent, d < cnt ? d : cnt - 1) * n;
 #pragma unroll
-      for (int r = 0; r < R; r++) pd[d][r] = states_in[prow + vcl[r]];
+      for (int r = 0; r < R; r++) pd[d][r] = SO ? cs_value(0) : states_in[prow + vcl[r]];
 #pragma unroll
       for (int q = 0; q < R * FW; q++)
         pf[d][q] = have_in ? forb_in2[(prow + vcl[q / FW]) * FW + (q % FW)] : make_uint2(0u, 0u);
@@ -1098,11 +1132,25 @@ __global__ __launch_bounds__(1024, (FW * R <= 1 ? 8 : 4)) void cs_propagate_ne_r
           }
         }
 
+        if (SO) {
+          /* the state IS the sets: every value outside a variable's interval is marked in its own set, so the
+           * interval is [lowest allowed, highest allowed] of the whole window */
+#pragma unroll
+          for (int r = 0; r < R; r++) {
+            int first, last;
+            cs_set_bounds<NW>(fb[r], 0, 32 * NW - 1, &first, &last);
+            lo[r] = live[r] ? b0[r] + first : 0; /* a state with an empty set of allowed values is not a valid input */
+            hi[r] = live[r] ? b0[r] + last : 0;
+          }
+        }
+
         /* the assignment (step_enter, csolve.c:294-304) and the first set of variables to push */
         unsigned long long push[R];
         const bool all_push = !have_in || nvar < 0;
 #pragma unroll
         for (int r = 0; r < R; r++) {
+          if ((SO || (flags & CS_K4_OUT_RESTRICT)) && nvar >= 0 && (nvar >> 6) == r && lane == (nvar & 63))
+            cs_set_restrict<NW>(fb[r], nlo - b0[r], nhi - b0[r]); /* the assignment becomes part of the set */
           if (nvar >= 0 && (nvar >> 6) == r && lane == (nvar & 63)) { lo[r] = nlo; hi[r] = nhi; }
           if (all_push) push[r] = __ballot(lo[r] == hi[r] && live[r]);
           else push[r] = (nlo == nhi && (nvar >> 6) == r) ? 1ull << (nvar & 63) : 0ull; /* scalar */
@@ -1155,19 +1203,8 @@ __global__ __launch_bounds__(1024, (FW * R <= 1 ? 8 : 4)) void cs_propagate_ne_r
           unsigned long long any = 0ull;
 #pragma unroll
           for (int r = 0; r < R; r++) {
-            const int from = lo[r] - b0[r], to = hi[r] - b0[r];
-            int first = 0x7fffffff, last = -1;
-#pragma unroll
-            for (int q = 0; q < NW; q++) {
-              const int f = from - 32 * q, t = to - 32 * q; /* the interval in this word's coordinates */
-              const unsigned mlo = f <= 0 ? ~0u : (f > 31 ? 0u : ~0u << (f & 31));
-              const unsigned mhi = t >= 31 ? ~0u : (t < 0 ? 0u : ~0u >> ((31 - t) & 31));
-              const unsigned a = ~fb[r][q] & mlo & mhi;
-              const int lo_q = a != 0u ? 32 * q + __builtin_ctz(a) : 0x7fffffff;
-              const int hi_q = a != 0u ? 32 * q + 31 - __builtin_clz(a) : -1;
-              first = lo_q < first ? lo_q : first;
-              last = hi_q > last ? hi_q : last;
-            }
+            int first, last;
+            cs_set_bounds<NW>(fb[r], lo[r] - b0[r], hi[r] - b0[r], &first, &last);
             const bool bad = last < 0; /* no allowed value in [lo, hi] (also when lo > hi) */
             const int nlo2 = b0[r] + first, nhi2 = b0[r] + last;
             const bool newly = !bad && (nlo2 != lo[r] || nhi2 != hi[r]) && nlo2 == nhi2;
@@ -1187,7 +1224,7 @@ __global__ __launch_bounds__(1024, (FW * R <= 1 ? 8 : 4)) void cs_propagate_ne_r
           const int jn = j + D < cnt ? j + D : cnt - 1;
           const size_t prow = (size_t)__builtin_amdgcn_readlane(rec.parent, jn) * n;
 #pragma unroll
-          for (int r = 0; r < R; r++) pd[dd][r] = states_in[prow + vcl[r]];
+          for (int r = 0; r < R; r++) pd[dd][r] = SO ? cs_value(0) : states_in[prow + vcl[r]];
 #pragma unroll
           for (int q = 0; q < R * FW; q++)
             pf[dd][q] = have_in ? forb_in2[(prow + vcl[q / FW]) * FW + (q % FW)] : make_uint2(0u, 0u);
@@ -1201,9 +1238,14 @@ __global__ __launch_bounds__(1024, (FW * R <= 1 ? 8 : 4)) void cs_propagate_ne_r
         }
         const int props = cs_wave_sum(shaved);
         const size_t orow = (size_t)(base + j) * n;
+        if (flags & CS_K4_OUT_RESTRICT) { /* packing: the interval goes into the set */
+#pragma unroll
+          for (int r = 0; r < R; r++) cs_set_restrict<NW>(fb[r], lo[r] - b0[r], hi[r] - b0[r]);
+        }
         if (FAST) {
 #pragma unroll
-          for (int r = 0; r < R; r++) states_out[orow + lane + r * CS_WAVE] = cs_interval(lo[r], hi[r]);
+          for (int r = 0; r < R; r++)
+            if (!SO) states_out[orow + lane + r * CS_WAVE] = cs_interval(lo[r], hi[r]);
 #pragma unroll
           for (int q = 0; q < R * FW; q++)
             forb_out2[(orow + lane + (q / FW) * CS_WAVE) * FW + (q % FW)] =
@@ -1211,7 +1253,7 @@ __global__ __launch_bounds__(1024, (FW * R <= 1 ? 8 : 4)) void cs_propagate_ne_r
         } else if (!failed) {
 #pragma unroll
           for (int r = 0; r < R; r++)
-            if (live[r]) states_out[orow + lane + r * CS_WAVE] = cs_interval(lo[r], hi[r]);
+            if (live[r] && !SO && states_out != nullptr) states_out[orow + lane + r * CS_WAVE] = cs_interval(lo[r], hi[r]);
           if (forb_out != nullptr) {
 #pragma unroll
             for (int q = 0; q < R * FW; q++)
@@ -1376,6 +1418,26 @@ __global__ __launch_bounds__(CS_BLOCK) void cs_eval_clauses(cs_tables T, const c
       v = S.val[len - 1];
     }
     vals[c] = v;
+  }
+}
+
+/* sets-only states -> intervals: [lowest allowed, highest allowed] per variable ({1, 0} when nothing is allowed) */
+template <int FW>
+__global__ void cs_sets_unpack(int n, const int *__restrict__ root_lo, const unsigned long long *__restrict__ sets,
+                               cs_val *__restrict__ states, long long count) {
+  const long long total = count * n;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int v = (int)(i % n);
+    unsigned w[2 * FW];
+#pragma unroll
+    for (int k = 0; k < FW; k++) {
+      const unsigned long long x = sets[i * FW + k];
+      w[2 * k] = (unsigned)x;
+      w[2 * k + 1] = (unsigned)(x >> 32);
+    }
+    int first, last;
+    cs_set_bounds<2 * FW>(w, 0, 64 * FW - 1, &first, &last);
+    states[i] = last < 0 ? cs_interval(1, 0) : cs_interval(root_lo[v] + first, root_lo[v] + last);
   }
 }
 

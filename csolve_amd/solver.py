@@ -197,6 +197,37 @@ class Model:
             _stream_ptr(stream)))
         return states_out, forb_out, results
 
+    # ---- sets-only states (csgpu_sets_*) ---------------------------------------------------------
+    def pack_sets(self, states: torch.Tensor, stream=None) -> torch.Tensor:
+        """interval states [k, n_vars, 2] -> sets-only states [k, n_vars, FW] (int64)"""
+        n, fw = self.n_vars, self.forbidden_words()
+        assert states.is_cuda and states.dtype == torch.int32 and states.is_contiguous() and states.shape[-2:] == (n, 2)
+        sets = torch.empty((states.shape[0], n, fw), dtype=torch.int64, device=states.device)
+        check(load_library().csgpu_sets_pack(self._h, states.data_ptr(), sets.data_ptr(), states.shape[0], _stream_ptr(stream)))
+        return sets
+
+    def unpack_sets(self, sets: torch.Tensor, stream=None) -> torch.Tensor:
+        n, fw = self.n_vars, self.forbidden_words()
+        assert sets.is_cuda and sets.dtype == torch.int64 and sets.is_contiguous() and sets.shape[-2:] == (n, fw)
+        states = torch.empty((sets.shape[0], n, 2), dtype=torch.int32, device=sets.device)
+        check(load_library().csgpu_sets_unpack(self._h, sets.data_ptr(), states.data_ptr(), sets.shape[0], _stream_ptr(stream)))
+        return states
+
+    def propagate_sets(self, sets_in: torch.Tensor, nodes: torch.Tensor, sets_out: torch.Tensor = None,
+                       results: torch.Tensor = None, stream=None):
+        """Batched propagate_clauses on sets-only states -> (sets_out [B, n_vars, FW], results [B, 4])"""
+        n, fw = self.n_vars, self.forbidden_words()
+        assert sets_in.is_cuda and sets_in.dtype == torch.int64 and sets_in.is_contiguous() and sets_in.shape[-2:] == (n, fw)
+        assert nodes.is_cuda and nodes.dtype == torch.int32 and nodes.is_contiguous() and nodes.shape[-1] == 4
+        B = nodes.shape[0]
+        if sets_out is None:
+            sets_out = torch.empty((B, n, fw), dtype=torch.int64, device=nodes.device)
+        if results is None:
+            results = torch.empty((B, 4), dtype=torch.int32, device=nodes.device)
+        check(load_library().csgpu_propagate_batch_sets(self._h, sets_in.data_ptr(), nodes.data_ptr(), sets_out.data_ptr(),
+                                                        results.data_ptr(), B, _stream_ptr(stream)))
+        return sets_out, results
+
     def eval_root(self, states: torch.Tensor, stream=None) -> torch.Tensor:
         """Three-valued value of the root wide-and per state: 1 true, 0 false, 2 undecided."""
         assert states.is_cuda and states.dtype == torch.int32 and states.is_contiguous()

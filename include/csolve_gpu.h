@@ -116,6 +116,21 @@ int csgpu_model_build_tables(csgpu_model *m);
  * CSGPU_E_UNBOUNDED if a variable still has an infinite bound. */
 int csgpu_model_finalize(csgpu_model *m);
 
+/* ---- sets-only states: the domains as bit vectors -------------------------------------------------------
+ * For models that qualify for kernel 4 a search state can be carried as its forbidden sets alone
+ * ([rows][n_vars][FW] 64-bit words, FW = csgpu_model_forbidden_words): every value outside a variable's
+ * interval is marked in the variable's own set, so the interval is [lowest unmarked, highest unmarked] and
+ * need not be stored.  Half the bytes per node of the interval + sets layout; same fixpoints, verdicts and
+ * PROPS (tests unpack and compare).
+ *   pack:    interval states -> sets (forbidden values of valued neighbours + everything outside the interval)
+ *   unpack:  sets -> interval states ({1,0} for a variable with no allowed value)
+ *   propagate_batch_sets: as csgpu_propagate_batch_fb, nodes[i].parent indexes d_sets_in; rows of inconsistent
+ *   nodes in d_sets_out are unspecified.  CSGPU_E_LIMIT if the model does not qualify. */
+int csgpu_sets_pack(const csgpu_model *m, const csgpu_val *d_states, uint64_t *d_sets, int64_t count, void *stream);
+int csgpu_sets_unpack(const csgpu_model *m, const uint64_t *d_sets, csgpu_val *d_states, int64_t count, void *stream);
+int csgpu_propagate_batch_sets(const csgpu_model *m, const uint64_t *d_sets_in, const csgpu_node *d_nodes,
+                               uint64_t *d_sets_out, csgpu_result *d_results, int64_t batch, void *stream);
+
 /* Kernel selection for the batched fixpoint: 0 = automatic (default), 1 = the general kernel
  * (adjacency read through L2; handles tree clauses), 2 = the LDS-resident unit-shaving kernel
  * (pure binary-NE models whose packed adjacency fits in LDS), 3 = the forbidden-set kernel (same

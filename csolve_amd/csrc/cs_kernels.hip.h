@@ -1034,6 +1034,25 @@ __device__ __forceinline__ void cs_set_bounds(const unsigned *w, int from, int t
   *last_out = last;
 }
 
+/* the same over the whole window -- for sets that already mark everything outside the variable's interval
+ * (sets-only states), where the range masks would be redundant */
+template <int NW>
+__device__ __forceinline__ void cs_set_bounds_all(const unsigned *w, int *first_out, int *last_out) {
+  int first = 0x7fffffff, last = -1;
+#pragma unroll
+  for (int q = NW - 1; q >= 0; q--) {
+    const unsigned a = ~w[q];
+    first = a != 0u ? 32 * q + __builtin_ctz(a) : first; /* lower words last: they win */
+  }
+#pragma unroll
+  for (int q = 0; q < NW; q++) {
+    const unsigned a = ~w[q];
+    last = a != 0u ? 32 * q + 31 - __builtin_clz(a) : last; /* higher words last: they win */
+  }
+  *first_out = first;
+  *last_out = last;
+}
+
 /* mark every value outside [from, to] (relative) as forbidden */
 template <int NW>
 __device__ __forceinline__ void cs_set_restrict(unsigned *w, int from, int to) {
@@ -1127,8 +1146,9 @@ __global__ __launch_bounds__(1024, (FW * R <= 1 ? 8 : 4)) void cs_propagate_ne_r
           hi[r] = live[r] ? pd[dd][r].hi : 0;
 #pragma unroll
           for (int k = 0; k < FW; k++) {
-            fb[r][2 * k] = live[r] ? pf[dd][r * FW + k].x : 0u;
-            fb[r][2 * k + 1] = live[r] ? pf[dd][r * FW + k].y : 0u;
+            /* a lane without a variable behaves like a variable fixed at its window's first value */
+            fb[r][2 * k] = live[r] ? pf[dd][r * FW + k].x : (k == 0 ? 0xfffffffeu : 0xffffffffu);
+            fb[r][2 * k + 1] = live[r] ? pf[dd][r * FW + k].y : 0xffffffffu;
           }
         }
 
@@ -1138,7 +1158,7 @@ __global__ __launch_bounds__(1024, (FW * R <= 1 ? 8 : 4)) void cs_propagate_ne_r
 #pragma unroll
           for (int r = 0; r < R; r++) {
             int first, last;
-            cs_set_bounds<NW>(fb[r], 0, 32 * NW - 1, &first, &last);
+            cs_set_bounds_all<NW>(fb[r], &first, &last);
             lo[r] = live[r] ? b0[r] + first : 0; /* a state with an empty set of allowed values is not a valid input */
             hi[r] = live[r] ? b0[r] + last : 0;
           }
@@ -1204,7 +1224,8 @@ __global__ __launch_bounds__(1024, (FW * R <= 1 ? 8 : 4)) void cs_propagate_ne_r
 #pragma unroll
           for (int r = 0; r < R; r++) {
             int first, last;
-            cs_set_bounds<NW>(fb[r], lo[r] - b0[r], hi[r] - b0[r], &first, &last);
+            if (SO) cs_set_bounds_all<NW>(fb[r], &first, &last); /* everything outside [lo, hi] is marked already */
+            else cs_set_bounds<NW>(fb[r], lo[r] - b0[r], hi[r] - b0[r], &first, &last);
             const bool bad = last < 0; /* no allowed value in [lo, hi] (also when lo > hi) */
             const int nlo2 = b0[r] + first, nhi2 = b0[r] + last;
             const bool newly = !bad && (nlo2 != lo[r] || nhi2 != hi[r]) && nlo2 == nhi2;

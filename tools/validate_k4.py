@@ -31,3 +31,17 @@ for rep in range(reps):
     if nb:
         print("rep", rep, "verdict mismatches", int(v.sum()), "state/set/props mismatches", int(s.sum()))
 print(f"queens-{nq}: {reps} launches x {count} nodes, mismatching nodes: {bad_total}  ({time.time()-t0:.1f} s)")
+
+# the sets-only layout of the same kernel: unpacked outputs against the same reference
+sets_in = model.pack_sets(states_in)
+bad_sets = 0
+for rep in range(reps):
+    so, rs = model.propagate_sets(sets_in, nodes)
+    torch.cuda.synchronize()
+    v = (rs[:, 0] >= 0) != ok
+    good = ok & ~v
+    un = model.unpack_sets(so)
+    s = good & ((un != o3).flatten(1).any(1) | (rs[:, :2] != r3[:, :2]).any(1))
+    bad_sets += int(v.sum()) + int(s.sum())
+print(f"queens-{nq} sets-only layout: {reps} launches x {count} nodes, mismatching nodes: {bad_sets}")
+

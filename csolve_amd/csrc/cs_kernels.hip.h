@@ -1169,8 +1169,10 @@ __global__ __launch_bounds__(1024, (FW * R <= 1 ? 8 : 4)) void cs_propagate_ne_r
         const bool all_push = !have_in || nvar < 0;
 #pragma unroll
         for (int r = 0; r < R; r++) {
-          if ((SO || (flags & CS_K4_OUT_RESTRICT)) && nvar >= 0 && (nvar >> 6) == r && lane == (nvar & 63))
-            cs_set_restrict<NW>(fb[r], nlo - b0[r], nhi - b0[r]); /* the assignment becomes part of the set */
+          if (SO || (flags & CS_K4_OUT_RESTRICT)) { /* uniform: the interval layout skips this altogether */
+            if (nvar >= 0 && (nvar >> 6) == r && lane == (nvar & 63))
+              cs_set_restrict<NW>(fb[r], nlo - b0[r], nhi - b0[r]); /* the assignment becomes part of the set */
+          }
           if (nvar >= 0 && (nvar >> 6) == r && lane == (nvar & 63)) { lo[r] = nlo; hi[r] = nhi; }
           if (all_push) push[r] = __ballot(lo[r] == hi[r] && live[r]);
           else push[r] = (nlo == nhi && (nvar >> 6) == r) ? 1ull << (nvar & 63) : 0ull; /* scalar */

@@ -357,16 +357,7 @@ extern "C" int csgpu_model_eval_clauses_host(csgpu_model *m, csgpu_val *vals) {
 static const void *ne_lds_kernel(int width, int n_vars) {
   int r = 1;
   while (r < 16 && r * CS_WAVE < n_vars) r <<= 1;
-  /* list strides fetched together; experiment knob, default 1 */
-  static int unroll = -1;
-  if (unroll < 0) {
-    const char *e = getenv("CSGPU_NE_UNROLL");
-    unroll = e != NULL && atoi(e) == 4 ? 4 : (e != NULL && atoi(e) == 2 ? 2 : 1);
-  }
-#define CS_PICK_U(E, RR)                                                                           \
-  return unroll == 4 ? (const void *)cs_propagate_ne_lds<E, RR, 4>                                  \
-                     : (unroll == 2 ? (const void *)cs_propagate_ne_lds<E, RR, 2>                    \
-                                    : (const void *)cs_propagate_ne_lds<E, RR, 1>);
+#define CS_PICK_U(E, RR) return (const void *)cs_propagate_ne_lds<E, RR, 1>;
 #define CS_PICK(E)                                                                                 \
   switch (r) {                                                                                     \
   case 1: CS_PICK_U(E, 1)                                                                          \
@@ -385,7 +376,6 @@ static const void *ne_bitset_kernel(int width, int fw, int n_vars) {
   /* prefetch depth R = ceil(n_vars/64) when that is 1, 2 or 4 (states of up to 256 variables) */
   const int chunks = (n_vars + CS_WAVE - 1) / CS_WAVE;
   int r = chunks <= 1 ? 1 : (chunks <= 2 ? 2 : (chunks <= 4 ? 4 : 0));
-  if (getenv("CSGPU_NO_PREFETCH") != NULL) r = 0;
 #define CS_PICK_R(E, F)                                                                            \
   switch (r) {                                                                                     \
   case 1: return (const void *)cs_propagate_ne_bitset<E, F, 1>;                                    \

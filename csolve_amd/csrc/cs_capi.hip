@@ -59,7 +59,10 @@ struct csgpu_model {
   void *d_sym_packed;
   int n_cus;
   /* staging of csgpu_propagate_one */
-  cs_val *d_one_in, *d_one_out;
+  /* pinned host memory mapped into the device's address space: the kernel reads the state and the node record
+   * from it and writes the result and the new state back, no staging copies */
+  unsigned char *h_one;          /* [state | node | result | state_out] */
+  cs_val *d_one_in, *d_one_out;  /* device views of the four parts */
   cs_node_in *d_one_node;
   cs_node_out *d_one_res;
 };
@@ -155,7 +158,8 @@ static void free_device(csgpu_model *m) {
   m->d_root_lo = NULL;
   m->lds_waves = 0;
   m->fb_words = 0;
-  (void)hipFree(m->d_one_in); (void)hipFree(m->d_one_out); (void)hipFree(m->d_one_node); (void)hipFree(m->d_one_res);
+  (void)hipHostFree(m->h_one);
+  m->h_one = NULL;
   m->d_adj_off = m->d_adj = m->d_clause = m->d_tree_off = m->d_tnode = m->d_tkid = NULL;
   m->d_one_in = m->d_one_out = NULL;
   m->d_one_node = NULL;
@@ -596,10 +600,16 @@ extern "C" int csgpu_model_finalize(csgpu_model *m) {
   m->n_cus = prop.multiProcessorCount;
 
   const size_t nbytes = (size_t)(h->n_vars ? h->n_vars : 1) * sizeof(cs_val);
-  HIP_TRY(hipMalloc((void **)&m->d_one_in, nbytes));
-  HIP_TRY(hipMalloc((void **)&m->d_one_out, nbytes));
-  HIP_TRY(hipMalloc((void **)&m->d_one_node, sizeof(cs_node_in)));
-  HIP_TRY(hipMalloc((void **)&m->d_one_res, sizeof(cs_node_out)));
+  {
+    const size_t part = (nbytes + 63) & ~(size_t)63;
+    unsigned char *dev = NULL;
+    HIP_TRY(hipHostMalloc((void **)&m->h_one, 2 * part + 128, hipHostMallocMapped));
+    HIP_TRY(hipHostGetDevicePointer((void **)&dev, m->h_one, 0));
+    m->d_one_in = (cs_val *)dev;
+    m->d_one_node = (cs_node_in *)(dev + part);
+    m->d_one_res = (cs_node_out *)(dev + part + 64);
+    m->d_one_out = (cs_val *)(dev + part + 128);
+  }
   m->finalized = 1;
   return CSGPU_OK;
 }
@@ -892,13 +902,15 @@ extern "C" int csgpu_propagate_one(const csgpu_model *m, const csgpu_val *state,
   if (m == NULL || state == NULL || state_out == NULL || result == NULL) return set_err(CSGPU_E_ARG, "null argument");
   if (!m->finalized) return set_err(CSGPU_E_STATE, "model is not finalized");
   const size_t nbytes = (size_t)m->host->n_vars * sizeof(cs_val);
+  const size_t part = (nbytes + 63) & ~(size_t)63;
   node.parent = 0;
-  HIP_TRY(hipMemcpy(m->d_one_in, state, nbytes, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(m->d_one_node, &node, sizeof node, hipMemcpyHostToDevice));
+  memcpy(m->h_one, state, nbytes);
+  memcpy(m->h_one + part, &node, sizeof node);
   int rc = csgpu_propagate_batch(m, (const csgpu_val *)m->d_one_in, (const csgpu_node *)m->d_one_node,
                                  (csgpu_val *)m->d_one_out, (csgpu_result *)m->d_one_res, 1, NULL);
   if (rc != CSGPU_OK) return rc;
-  HIP_TRY(hipMemcpy(result, m->d_one_res, sizeof *result, hipMemcpyDeviceToHost));
-  if (result->status >= 0) HIP_TRY(hipMemcpy(state_out, m->d_one_out, nbytes, hipMemcpyDeviceToHost));
+  HIP_TRY(hipStreamSynchronize(NULL)); /* one launch, one wait: the kernel worked on the mapped host buffers */
+  memcpy(result, m->h_one + part + 64, sizeof *result);
+  if (result->status >= 0) memcpy(state_out, m->h_one + part + 128, nbytes);
   return CSGPU_OK;
 }

@@ -234,7 +234,7 @@ def search_workload(args, rank, world, local, dist):
         eng.reset()
         sh = ShardedSearch(eng, model.objective, n, rank, world, dist, engine_device="cuda", comm_device=comm,
                            slice_iterations=args.slice, seed_states_per_rank=256, low_water=4096)
-        local_stats, totals = sh.run(model.root_state())
+        local_stats, totals = sh.run(model.root_state(), args.search_slices if args.search_slices > 0 else 1 << 40)
         return local_stats, totals, sh
 
     def barrier():
@@ -271,7 +271,8 @@ def search_workload(args, rank, world, local, dist):
                                    f"(BASELINE configs[3] shape)", "solutions": totals["solutions"],
                        "nodes": totals["nodes"], "cuts": totals["cuts"], "props": totals["props"],
                        "iterations": totals["iterations"], "states_moved_between_ranks": int(moved.item()),
-                       "nodes_per_rank": share.cpu().tolist(), "comm": args.comm}}))
+                       "nodes_per_rank": share.cpu().tolist(), "comm": args.comm,
+                       "stopped_after_slices": args.search_slices or None}}))
 
 
 def main():
@@ -298,6 +299,8 @@ def main():
     ap.add_argument("--pool", type=int, default=1 << 22)
     ap.add_argument("--children", type=int, default=1 << 19)
     ap.add_argument("--slice", type=int, default=32, help="search iterations between rank exchanges")
+    ap.add_argument("--search-slices", type=int, default=0,
+                    help="stop a search after this many slices (0 = run to the end): ALL on trees too large to finish")
     ap.add_argument("--comm", choices=["nccl", "gloo"], default="nccl")
     ap.add_argument("--same-device", action="store_true", help="all ranks on cuda:0 (rehearsal on a 1-GPU box, use --comm gloo)")
     args = ap.parse_args()

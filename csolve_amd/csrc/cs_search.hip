@@ -27,6 +27,7 @@ struct csgpu_search {
   const csgpu_model *m;
   int n, objective, obj_var;
   int64_t cap, max_children, max_parents, max_width, parents_limit;
+  double avg_children; /* children per parent of the recent iterations (ALL sizes its batches by it) */
   cs_val *pool;
   int64_t top, peak;
   /* forbidden sets travelling with the states (pure binary-NE models, csgpu_propagate_batch_fb) */
@@ -551,6 +552,7 @@ extern "C" int csgpu_search_create(const csgpu_model *m, int64_t pool_capacity, 
   /* ALL walks the whole tree anyway: widest batches.  ANY/MIN/MAX profit from going deep first
    * (a first solution / a good incumbent early prunes everything else), so only the newest 64
    * open states are expanded per iteration. */
+  s->avg_children = (double)s->max_width;
   s->parents_limit = csgpu_model_objective(m) == CS_OBJ_ALL ? s->max_parents : 64;
   if (s->parents_limit > s->max_parents) s->parents_limit = s->max_parents;
   if (pool_capacity < max_children + 1) pool_capacity = max_children + 1;
@@ -575,9 +577,10 @@ extern "C" int csgpu_search_create(const csgpu_model *m, int64_t pool_capacity, 
     ALLOC(s->d_child_forb, (size_t)n * s->fw * 8 * (size_t)max_children);
     ALLOC(s->d_rebuild_nodes, sizeof(csgpu_node) * (size_t)max_children);
   }
-  ALLOC(s->d_branch_var, sizeof(int) * (size_t)s->max_parents);
-  ALLOC(s->d_child_count, sizeof(int) * (size_t)s->max_parents);
-  ALLOC(s->d_child_off, sizeof(int) * ((size_t)s->max_parents + 1));
+  /* up to max_children / 2 parents when every parent has two children */
+  ALLOC(s->d_branch_var, sizeof(int) * (size_t)max_children);
+  ALLOC(s->d_child_count, sizeof(int) * (size_t)max_children);
+  ALLOC(s->d_child_off, sizeof(int) * ((size_t)max_children + 1));
   ALLOC(s->d_nodes, sizeof(csgpu_node) * (size_t)max_children);
   ALLOC(s->d_child_states, row * (size_t)max_children);
   ALLOC(s->d_complete_states, row * (size_t)max_children);
@@ -750,14 +753,34 @@ static int flush_accept_results(csgpu_search *s) {
 static int one_iteration(csgpu_search *s) {
   const int n = s->n;
   int64_t parents = s->top < s->parents_limit ? s->top : s->parents_limit;
-  /* survivors go back above the consumed parents: guaranteed room for max_children rows */
-  if (s->top - parents + s->max_children > s->cap) {
-    parents = s->top < 1 ? 0 : 1; /* a nearly full pool: fall back to strict depth-first */
-    if (s->top - parents + s->max_width > s->cap) return fail(CSGPU_E_LIMIT, "state pool is full");
+  const int64_t reserve = (int64_t)s->n * s->max_width;
+  const int64_t room_limit = s->cap > reserve ? s->cap - reserve : s->cap;
+  /* ALL walks the whole tree: batches as large as the child buffers allow.  How many parents that is depends on
+   * how wide they branch, which is only known after cs_branch; the recent average sizes the attempt (the exact
+   * count is checked below and the attempt halved if it does not fit). */
+  const int adaptive = s->objective == CS_OBJ_ALL && s->parents_limit == s->max_parents;
+  if (adaptive) {
+    int64_t guess = (int64_t)((double)s->max_children / (s->avg_children * 1.25));
+    if (guess > s->max_children / 2) guess = s->max_children / 2;
+    /* and as many as the pool is likely to have room for */
+    const double per_parent = s->avg_children > 1.5 ? s->avg_children - 1.0 : 0.5;
+    const int64_t room = (int64_t)((double)(room_limit - s->top) / (per_parent * 1.25));
+    if (guess > room) guess = room;
+    if (guess > parents) parents = guess < s->top ? guess : s->top;
   }
-  const long long first_row = s->top - parents;
+  /* the children of p parents need at most p * max_width rows above the top - p that stay.  A nearly full pool
+   * takes as many parents as are guaranteed to fit below a reserve of n_vars * max_width rows, and one parent
+   * (strict depth-first, which cannot grow the pool by more than that reserve) once the reserve is reached */
+  if (!adaptive || parents <= s->max_parents) {
+    if (s->top - parents + parents * s->max_width > room_limit) {
+      const int64_t fit = s->max_width > 1 ? (room_limit - s->top) / (s->max_width - 1) : parents;
+      parents = s->top < 1 ? 0 : (fit < 1 ? 1 : (fit < parents ? fit : parents));
+      if (s->top - parents + parents * s->max_width > s->cap) return fail(CSGPU_E_LIMIT, "state pool is full");
+    }
+  }
+  long long first_row = s->top - parents;
   if (parents == 0) return CSGPU_OK;
-  const int small = parents <= SMALL_PARENTS;
+  const int small = parents <= SMALL_PARENTS && parents <= s->max_parents;
   const int low_last = s->objective == CS_OBJ_MAX ? 0 : 1;
   const unsigned scramble =
       s->objective == CS_OBJ_ANY ? (unsigned)(s->st.iterations * 2654435761ull + 0x9e3779b9u) | 1u : 0u;
@@ -775,19 +798,30 @@ static int one_iteration(csgpu_search *s) {
     d_children = (const uint64_t *)(s->d_counters + C_TOTAL_CHILDREN);
   } else {
     HIP_OK(hipMemsetAsync(s->d_counters, 0, sizeof(unsigned long long) * C_PER_ITERATION, 0));
-    const unsigned pb = (unsigned)((parents + 3) / 4);
-    hipLaunchKernelGGL(cs_branch, dim3(pb), dim3(SB), 0, 0, s->pool, first_row, (int)parents, n, s->d_branch_var,
-                       s->d_child_count);
-    hipLaunchKernelGGL(cs_scan, dim3(1), dim3(1024), 0, 0, s->d_child_count, (int)parents, s->d_child_off, s->d_counters,
-                       (int)C_TOTAL_CHILDREN);
-    /* first host read of the iteration: the number of children, and with it what the previous
-     * iteration's accept left behind (solutions so far, incumbent) */
-    unsigned long long head[C_COUNT - C_TOTAL_CHILDREN];
-    HIP_OK(hipMemcpy(head, s->d_counters + C_TOTAL_CHILDREN, sizeof head, hipMemcpyDeviceToHost));
-    children = (int64_t)head[0];
+    unsigned pb;
+    for (;;) {
+      pb = (unsigned)((parents + 3) / 4);
+      hipLaunchKernelGGL(cs_branch, dim3(pb), dim3(SB), 0, 0, s->pool, first_row, (int)parents, n, s->d_branch_var,
+                         s->d_child_count);
+      hipLaunchKernelGGL(cs_scan, dim3(1), dim3(1024), 0, 0, s->d_child_count, (int)parents, s->d_child_off,
+                         s->d_counters, (int)C_TOTAL_CHILDREN);
+      /* first host read of the iteration: the number of children, and with it what the previous
+       * iteration's accept left behind (solutions so far, incumbent) */
+      unsigned long long head[C_COUNT - C_TOTAL_CHILDREN];
+      HIP_OK(hipMemcpy(head, s->d_counters + C_TOTAL_CHILDREN, sizeof head, hipMemcpyDeviceToHost));
+      children = (int64_t)head[0];
+      int rc0 = apply_accept_results(s, head[C_SOLUTIONS - C_TOTAL_CHILDREN], (int)(unsigned)head[C_BEST - C_TOTAL_CHILDREN]);
+      if (rc0 != CSGPU_OK) return rc0;
+      if (adaptive) s->avg_children = 0.5 * s->avg_children + 0.5 * ((double)children / (double)parents);
+      /* the exact fit: the child buffers, and the pool rows above the parents that stay */
+      const int fits = children <= s->max_children &&
+                       (s->top - parents + children <= room_limit || (parents == 1 && s->top - 1 + children <= s->cap));
+      if (fits) break;
+      if (parents == 1) return fail(CSGPU_E_LIMIT, "state pool is full");
+      parents = parents / 2 > 0 ? parents / 2 : 1;
+      first_row = s->top - parents;
+    }
     d_children = NULL;
-    int rc0 = apply_accept_results(s, head[C_SOLUTIONS - C_TOTAL_CHILDREN], (int)(unsigned)head[C_BEST - C_TOTAL_CHILDREN]);
-    if (rc0 != CSGPU_OK) return rc0;
     if (children > s->max_children) return fail(CSGPU_E_LIMIT, "internal: more children than the batch buffers hold");
     hipLaunchKernelGGL(cs_emit, dim3(pb), dim3(SB), 0, 0, s->pool, first_row, (int)parents, n, s->d_branch_var,
                        s->d_child_off, s->d_nodes, low_last, scramble);

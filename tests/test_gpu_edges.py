@@ -123,3 +123,27 @@ def test_empty_batch_and_repeated_parents():
     out, res = model.propagate(states, nodes)
     torch.cuda.synchronize()
     assert torch.equal(out[0], out[1]) and torch.equal(out[0], out[2]) and torch.equal(res[0], res[1])
+
+
+def test_sets_only_layout_limits_and_empty_batches():
+    """csgpu_sets_*: a model that does not qualify for kernel 4 is refused (CSGPU_E_LIMIT), empty batches are
+    accepted, a state without allowed values unpacks to the empty interval {1, 0}."""
+    from csolve_amd import problems
+    from csolve_amd._lib import CsolveError
+    from csolve_amd.solver import solve_root
+    big = solve_root(problems.sudoku(5, 0.4, 1))  # 625 variables: kernel 3 only
+    assert big.forbidden_words() == 1 and not big.qualifies(4)
+    with pytest.raises(CsolveError):
+        big.pack_sets(big.root_state())
+    model = solve_root(problems.queens(12))
+    root = model.root_state()
+    sets = model.pack_sets(root)
+    empty_nodes = torch.empty((0, 4), dtype=torch.int32, device="cuda")
+    out, res = model.propagate_sets(sets, empty_nodes)
+    assert out.shape[0] == 0 and res.shape[0] == 0
+    assert model.pack_sets(root[:0].contiguous()).shape[0] == 0
+    assert model.unpack_sets(sets[:0].contiguous()).shape[0] == 0
+    dead = sets.clone()
+    dead[0, 3, :] = -1  # every value of variable 3 marked
+    un = model.unpack_sets(dead)
+    assert un[0, 3].tolist() == [1, 0] and torch.equal(un[0, :3], root[0, :3])

@@ -185,3 +185,12 @@ def test_two_engines_share_the_incumbent():
     assert min(sa["best"], sb["best"]) == 31
     row = a.best_solution() if sa["best"] == 31 and a.best_solution() is not None else b.best_solution()
     assert row is not None and row[model.objective_var] == 31
+
+
+@pytest.mark.parametrize("pool,children", [(600, 128), (2000, 1024), (40000, 4096)])
+def test_small_pools_still_walk_the_whole_tree(pool, children):
+    """A pool that is far too small for breadth: the engine sizes its batches by what fits (and falls back to
+    depth-first below its reserve) and still finds every solution exactly once."""
+    from csolve_amd import problems
+    model, s, st = _solve(problems.queens(10, "ALL"), pool=pool, children=children)
+    assert st["done"] == 1 and st["solutions"] == 724 and st["pool_peak"] <= max(pool, children + 1)

@@ -17,9 +17,15 @@ nodes are independent, so the data path has no collective.
 
 Prints ONE JSON line (rank 0): value = narrowing events ("propagations", the reference's
 PROPS counter, propagate.c:77-78) per second over all ranks; `roofline` for the fixpoint
-kernel from HIP-event timing; `cpu_baseline` = the CPU oracle (a bit-checked restatement
-of the reference propagator) timed on one host core on a bounded sample of the same
-instances, which also re-checks the device results on that sample.
+kernel from HIP-event timing; `cpu_baseline` = the compiled reference itself
+(oracle/_ref/csolve_ref, kind "reference"; the oracle restatement, kind "port", when that
+binary is absent) replaying the same instances on one host core -- and, as `all_cores`,
+as independent processes on all of them -- which also re-checks every device result of the
+sample bit for bit.
+
+Other workloads: --queens N, --sudoku N, --schedule N (propagation-only on other model
+shapes), --layout sets (the states carried as bit vectors only), --workload search (the
+sharded search engine, strong scaling).
 """
 import argparse
 import json

@@ -3,7 +3,15 @@
  * Written for CDNA4 only: 64-lane wavefronts, LDS-resident node state, wave-level
  * ballots.  No MFMA: the work is integer compare / select / LDS atomics.
  *
- * Execution model of the hot kernel (cs_propagate_events):
+ * Kernels in this file (all compute the batched propagate_clauses fixpoint with the same results):
+ *   cs_propagate_events   (1) any model: binary relations inline, other clauses through the tree interpreter
+ *   cs_propagate_ne_lds   (2) pure binary-!= models, adjacency in LDS, unit shaving
+ *   cs_propagate_ne_bitset(3) the same models with forbidden sets per variable in LDS
+ *   cs_propagate_ne_regs  (4) models of at most 256 variables: sets and bounds in registers (the bench kernel),
+ *                             also with the states carried as the sets alone
+ *   cs_propagate_sweeps, cs_eval_root, cs_eval_clauses, cs_sets_unpack: root phase, evaluation, layout helper
+ *
+ * Execution model of the general kernel (cs_propagate_events):
  *   - one WAVEFRONT owns one search node; a 256-thread workgroup is four independent
  *     nodes, there is no __syncthreads() anywhere in the kernel;
  *   - the node's interval domains (n_vars x {lo,hi}, 8 B each, the reference's
@@ -26,6 +34,7 @@
  *   propagate_eq/lt/neg/add/mul/not/and/or/wand  propagate.c:139-392 -> cs_tree_revise
  *   eval_*              eval.c:27-255         -> cs_tree_eval (+ cs_arith.h)
  *   NOT(EQ(x+k, y+l))   propagate.c:289-301,123-136,106-120,223-246 -> cs_ne_revise
+ *   x = y+c, x < y+c, not(x < y), (a < b+c) or (d < e+f)      propagate.c:139-246, 289-340 -> cs_lin_revise, cs_or2_revise
  * The revision ORDER differs from the reference (parallel rounds instead of depth-first
  * recursion); the fixpoint and the consistent/inconsistent verdict do not.
  */

@@ -230,6 +230,10 @@ def search_workload(args, rank, world, local, dist):
     from csolve_amd.parallel import ShardedSearch
     from csolve_amd.solver import Search
     text = problems.queens(args.search_queens, args.search_objective)
+    what = f"queens-{args.search_queens} {args.search_objective}"
+    if args.search_schedule:
+        text = problems.schedule(args.search_schedule, 1)
+        what = f"schedule-{args.search_schedule} MIN (examples/schedule.txt style)"
     model = solve_root(text)
     n = model.n_vars
     comm = "cpu" if args.comm == "gloo" else "cuda"
@@ -273,8 +277,9 @@ def search_workload(args, rank, world, local, dist):
             "nodes_per_s": totals["nodes"] * args.steps / elapsed, "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": f"queens-{args.search_queens} {args.search_objective}, full search sharded GPU-per-subtree "
-                                   f"(BASELINE configs[3] shape)", "solutions": totals["solutions"],
+            "config": {"workload": f"{what}, full search sharded GPU-per-subtree "
+                                   f"(BASELINE configs[{4 if args.search_schedule else 3}] shape)", "solutions": totals["solutions"],
+                       "best": totals.get("best") if args.search_schedule else None,
                        "nodes": totals["nodes"], "cuts": totals["cuts"], "props": totals["props"],
                        "iterations": totals["iterations"], "states_moved_between_ranks": int(moved.item()),
                        "nodes_per_rank": share.cpu().tolist(), "comm": args.comm,
@@ -303,6 +308,8 @@ def main():
     ap.add_argument("--workload", choices=["propagate", "search"], default="propagate")
     ap.add_argument("--search-queens", type=int, default=13)
     ap.add_argument("--search-objective", choices=["ALL", "ANY"], default="ALL")
+    ap.add_argument("--search-schedule", type=int, default=0, help="search workload on a schedule.txt-style MIN model of this "
+                    "many tasks instead of queens (BASELINE configs[4] shape: the incumbent bound travels between the ranks)")
     ap.add_argument("--pool", type=int, default=1 << 22)
     ap.add_argument("--children", type=int, default=1 << 19)
     ap.add_argument("--slice", type=int, default=32, help="search iterations between rank exchanges")

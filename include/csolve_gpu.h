@@ -174,7 +174,9 @@ int csgpu_propagate_batch_obj(const csgpu_model *m, const csgpu_val *d_states_in
  * derived data that the search keeps next to each state so that a child inherits them:
  *   d_forb_in  [*][n_vars][FW] uint64, rows parallel to d_states_in  (NULL: rebuild from the state)
  *   d_forb_out [batch][n_vars][FW] uint64, rows parallel to d_states_out (NULL: not wanted)
- * Results (fixpoints, verdicts, PROPS of consistent nodes) are those of csgpu_propagate_batch. */
+ * Results (fixpoints, verdicts, PROPS of consistent nodes) are those of csgpu_propagate_batch.
+ * Rows of inconsistent nodes (status -1) in d_states_out / d_forb_out are unspecified: the register-resident
+ * kernel stores them unconditionally, the other kernels leave them untouched. */
 int csgpu_model_forbidden_words(const csgpu_model *m); /* 0: the model does not qualify */
 int csgpu_propagate_batch_fb(const csgpu_model *m, const csgpu_val *d_states_in, const uint64_t *d_forb_in,
                              const csgpu_node *d_nodes, csgpu_val *d_states_out, uint64_t *d_forb_out,

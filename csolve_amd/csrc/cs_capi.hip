@@ -48,6 +48,7 @@ struct csgpu_model {
   void *d_adj_packed;
   int lds_waves;     /* waves per workgroup of the LDS-resident kernel, 0 = not eligible */
   size_t lds_bytes;  /* its dynamic LDS size */
+  size_t k1_tab_bytes; /* general kernel: adj_off + adj + lit copied into LDS by every workgroup (0: read through L2) */
   int fb_words;      /* forbidden-set words per variable (0 = not eligible) */
   int fb_waves;
   size_t fb_bytes;
@@ -252,6 +253,7 @@ static int upload_image(const cs_dev_image *g, dev_tables_owner *o, cs_tables *t
   t->tkid = o->tkid;
   t->tree_want = (const int2 *)o->tree_want;
   t->lit = (const int4 *)o->lit;
+  t->n_lits = g->n_lits;
   t->obj_var = -1;
   t->obj_lo = CS_DOM_MIN;
   t->obj_hi = CS_DOM_MAX;
@@ -506,9 +508,17 @@ extern "C" int csgpu_model_finalize(csgpu_model *m) {
   m->has_tree_adj = 0;
   for (int32_t i = 0; i < m->img->n_adj; i++)
     if (m->img->adj[2 * i] < 0 && m->img->adj[2 * i + 1] == 0) { m->has_tree_adj = 1; break; }
-  const size_t lds = m->slice * CS_WAVES_PER_BLOCK;
-  if ((rc = lds_limit(lds, (const void *)cs_propagate_events<false>))) return rc;
-  if ((rc = lds_limit(lds, (const void *)cs_propagate_events<true>))) return rc;
+  /* small tables travel into LDS with every workgroup of the general kernel */
+  {
+    const size_t tb = ((((size_t)h->n_vars + 1) * 4 + 15) & ~(size_t)15) + (((size_t)m->img->n_adj * 8 + 15) & ~(size_t)15) +
+                      (((size_t)m->img->n_lits * 16 + 15) & ~(size_t)15);
+    m->k1_tab_bytes = (tb <= 32u * 1024u && m->img->n_adj > 0) ? tb : 0;
+  }
+  const size_t lds = m->slice * CS_WAVES_PER_BLOCK + m->k1_tab_bytes;
+  if ((rc = lds_limit(lds, (const void *)cs_propagate_events<false, false>))) return rc;
+  if ((rc = lds_limit(lds, (const void *)cs_propagate_events<true, false>))) return rc;
+  if ((rc = lds_limit(lds, (const void *)cs_propagate_events<false, true>))) return rc;
+  if ((rc = lds_limit(lds, (const void *)cs_propagate_events<true, true>))) return rc;
   if ((rc = lds_limit((size_t)h->n_vars * sizeof(cs_val) + 16, (const void *)cs_eval_root))) return rc;
   if ((rc = lds_limit((size_t)h->n_vars * sizeof(cs_val) + 16, (const void *)cs_eval_clauses))) return rc;
 
@@ -820,7 +830,7 @@ extern "C" int csgpu_internal_propagate_obj(const csgpu_model *m, const csgpu_va
   if (batch == 0) return CSGPU_OK; /* an empty batch needs no buffers */
   if (d_states_in == NULL || d_nodes == NULL || d_states_out == NULL || d_results == NULL)
     return set_err(CSGPU_E_ARG, "null argument");
-  const size_t lds = m->slice * CS_WAVES_PER_BLOCK;
+  const size_t lds = m->slice * CS_WAVES_PER_BLOCK + m->k1_tab_bytes;
   /* resident workgroups per CU: LDS- and wave-slot-limited (32 waves per CU) */
   size_t per_cu = (160u * 1024u) / lds;
   if (per_cu > 32 / CS_WAVES_PER_BLOCK) per_cu = 32 / CS_WAVES_PER_BLOCK;
@@ -861,12 +871,18 @@ extern "C" int csgpu_internal_propagate_obj(const csgpu_model *m, const csgpu_va
                             m->lds_bytes, s));
     return CSGPU_OK;
   }
-  if (m->has_tree_adj)
-    hipLaunchKernelGGL(cs_propagate_events<true>, dim3((unsigned)blocks), dim3(CS_BLOCK), lds, s, tab, in, nodes, out,
-                       res, (long long)batch, bdev);
+  if (m->has_tree_adj && m->k1_tab_bytes)
+    hipLaunchKernelGGL((cs_propagate_events<true, true>), dim3((unsigned)blocks), dim3(CS_BLOCK), lds, s, tab, in, nodes,
+                       out, res, (long long)batch, bdev);
+  else if (m->has_tree_adj)
+    hipLaunchKernelGGL((cs_propagate_events<true, false>), dim3((unsigned)blocks), dim3(CS_BLOCK), lds, s, tab, in, nodes,
+                       out, res, (long long)batch, bdev);
+  else if (m->k1_tab_bytes)
+    hipLaunchKernelGGL((cs_propagate_events<false, true>), dim3((unsigned)blocks), dim3(CS_BLOCK), lds, s, tab, in, nodes,
+                       out, res, (long long)batch, bdev);
   else
-    hipLaunchKernelGGL(cs_propagate_events<false>, dim3((unsigned)blocks), dim3(CS_BLOCK), lds, s, tab, in, nodes, out,
-                       res, (long long)batch, bdev);
+    hipLaunchKernelGGL((cs_propagate_events<false, false>), dim3((unsigned)blocks), dim3(CS_BLOCK), lds, s, tab, in, nodes,
+                       out, res, (long long)batch, bdev);
   HIP_TRY(hipGetLastError());
   return CSGPU_OK;
 }

@@ -61,6 +61,7 @@ struct cs_tables {
   const int *tkid;
   const int2 *tree_want;
   const int4 *lit; /* literals {a, b, d, 0} of the two-literal disjunctions: X_a < X_b + d */
+  int n_lits;
   /* objective bound applied to every node before it is propagated (objective_update_val,
    * reference src/objective.c:101-126): dom[obj_var] is intersected with [obj_lo, obj_hi] */
   int obj_var, obj_lo, obj_hi;
@@ -358,7 +359,9 @@ __device__ inline void cs_tree_revise(const cs_tables &T, int tree, cs_ctx &cx, 
 
 /* ---- the hot kernel: event-driven fixpoint, one wave per node ------------------- */
 
-template <bool HAS_TREE>
+/* TAB_LDS: adj_off, adj and lit are copied into LDS by every workgroup (small models: the inner loop then
+ * never waits for L2); the per-wave slices follow the tables */
+template <bool HAS_TREE, bool TAB_LDS>
 __global__ __launch_bounds__(CS_BLOCK) void cs_propagate_events(cs_tables T, const cs_val *__restrict__ states_in,
                                                                 const cs_node_in *__restrict__ nodes,
                                                                 cs_val *__restrict__ states_out,
@@ -370,10 +373,24 @@ __global__ __launch_bounds__(CS_BLOCK) void cs_propagate_events(cs_tables T, con
   const int n = T.n_vars, nw = T.n_words;
   /* the search engine launches for an upper bound and leaves the real count on the device */
   if (batch_dev != nullptr && (long long)*batch_dev < batch) batch = (long long)*batch_dev;
+  /* tables (TAB_LDS): adj_off[n+1] | adj[n_adj] | lit[n_lits], each padded to 16 bytes */
+  const int n_adj = TAB_LDS ? T.adj_off[n] : 0;
+  const size_t off_bytes = TAB_LDS ? ((((size_t)n + 1) * sizeof(int) + 15) & ~(size_t)15) : 0;
+  const size_t adj_bytes = TAB_LDS ? (((size_t)n_adj * sizeof(int2) + 15) & ~(size_t)15) : 0;
+  const size_t lit_bytes = TAB_LDS ? (((size_t)T.n_lits * sizeof(int4) + 15) & ~(size_t)15) : 0;
+  int *s_adj_off = (int *)cs_lds;
+  int2 *s_adj = (int2 *)(cs_lds + off_bytes);
+  int4 *s_lit = (int4 *)(cs_lds + off_bytes + adj_bytes);
+  if (TAB_LDS) {
+    for (int i = threadIdx.x; i <= n; i += blockDim.x) s_adj_off[i] = T.adj_off[i];
+    for (int i = threadIdx.x; i < n_adj; i += blockDim.x) s_adj[i] = T.adj[i];
+    for (int i = threadIdx.x; i < T.n_lits; i += blockDim.x) s_lit[i] = T.lit[i];
+    __syncthreads();
+  }
   /* per-wave LDS slice: domains, then the two changed masks */
   const size_t slice = (size_t)n * sizeof(cs_val) + 2 * (size_t)nw * sizeof(unsigned);
   const size_t slice_al = (slice + 15) & ~(size_t)15;
-  cs_val *dom = (cs_val *)(cs_lds + wave_in_block * slice_al);
+  cs_val *dom = (cs_val *)(cs_lds + off_bytes + adj_bytes + lit_bytes + wave_in_block * slice_al);
   unsigned *mask_a = (unsigned *)(dom + n);
   unsigned *mask_b = mask_a + nw;
 
@@ -445,13 +462,14 @@ __global__ __launch_bounds__(CS_BLOCK) void cs_propagate_events(cs_tables T, con
           /* a variable whose bounds crossed through racing lo/hi updates */
           const cs_val du = dom[u];
           if (du.lo > du.hi) cx.fail = 1;
-          const int beg = T.adj_off[u], end = T.adj_off[u + 1];
+          const int beg = TAB_LDS ? s_adj_off[u] : T.adj_off[u], end = TAB_LDS ? s_adj_off[u + 1] : T.adj_off[u + 1];
           for (int i = beg + lane; i < end && !cx.fail; i += CS_WAVE) {
-            const int2 e = T.adj[i];
+            const int2 e = TAB_LDS ? s_adj[i] : T.adj[i];
             if (e.x >= 0) {
               cs_lin_revise(cx, u, e.x & CS_ADJ_VAR_MASK, e.y, e.x >> 28);
             } else if (e.y != 0) {
-              cs_or2_revise(cx, T.lit + ~e.x);
+              if (TAB_LDS) cs_or2_revise(cx, s_lit + ~e.x);
+              else cs_or2_revise(cx, T.lit + ~e.x);
             } else if (HAS_TREE) {
               cs_tree_scratch S;
               cs_tree_revise(T, ~e.x, cx, S);

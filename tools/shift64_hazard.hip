@@ -22,13 +22,24 @@ __global__ __launch_bounds__(256) void probe(unsigned long long *bad, int iters)
       asm volatile("v_lshlrev_b64 %0, %1, 1\n\tv_add_u32 %1, 17, %1\n\tv_mov_b32 %1, 0" : "=&v"(x), "+v"(amt));
     } else if (MODE == 2) { /* B: the compiler's own code, result consumed at once */
       x = 1ull << amt;
-    } else { /* C: the sequence of the failing loop: shift, compare on the amount, select on the high half, amount overwritten */
+    } else if (MODE == 3) { /* C: the sequence of the failing loop: shift, compare on the amount, select on the high half, amount overwritten */
       unsigned sel, xl, xh;
       asm volatile("v_lshlrev_b64 v[40:41], %0, 1\n\tv_cmp_gt_u32 vcc, 64, %0\n\ts_add_i32 s0, s0, 0\n\tv_add_u32 %1, 0xc0, %0\n\t"
                    "v_cndmask_b32 %0, 0, v41, vcc\n\tv_mov_b32 %2, v40\n\tv_mov_b32 %3, v41"
                    : "+v"(amt), "=&v"(sel), "=&v"(xl), "=&v"(xh) : : "vcc", "s0", "v40", "v41");
       (void)sel;
       x = ((unsigned long long)xh << 32) | xl;
+    }
+    if (MODE == 4) { /* E: a 32-bit VALU op reads v60 / v61, the 64-bit shift right behind it overwrites v[60:61] */
+      const unsigned a = s * 2654435761u + 12345u, b = ~a * 40503u, y = s * 97u + 1u;
+      unsigned o1, o2, rl, rh;
+      asm volatile("v_mov_b32 v60, %4\n\tv_mov_b32 v61, %5\n\ts_nop 4\n\t"
+                   "v_or_b32 %0, v61, %6\n\tv_or_b32 %1, v60, %6\n\tv_lshlrev_b64 v[60:61], %7, 1\n\t"
+                   "s_nop 7\n\tv_mov_b32 %2, v60\n\tv_mov_b32 %3, v61"
+                   : "=&v"(o1), "=&v"(o2), "=&v"(rl), "=&v"(rh) : "v"(a), "v"(b), "v"(y), "v"(amt) : "v60", "v61");
+      wrong += (o1 != (b | y)) | (o2 != (a | y)) | (rl != want_lo) | (rh != want_hi);
+      s = (s * 5u + 3u) & 63u;
+      continue;
     }
     lo = (unsigned)x; hi = (unsigned)(x >> 32);
     wrong += (lo != want_lo) | (hi != want_hi);
@@ -43,14 +54,15 @@ int main() {
   hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
   const int iters = 20000;
   for (int wgs_per_cu = 1; wgs_per_cu <= 8; wgs_per_cu *= 8) {
-    for (int mode = 0; mode < 4; mode++) {
+    for (int mode = 0; mode < 5; mode++) {
       CHECK(hipMemset(d_bad, 0, 8));
       const int grid = prop.multiProcessorCount * wgs_per_cu;
       switch (mode) {
       case 0: hipLaunchKernelGGL(probe<0>, dim3(grid), dim3(256), 0, 0, d_bad, iters); break;
       case 1: hipLaunchKernelGGL(probe<1>, dim3(grid), dim3(256), 0, 0, d_bad, iters); break;
       case 2: hipLaunchKernelGGL(probe<2>, dim3(grid), dim3(256), 0, 0, d_bad, iters); break;
-      default: hipLaunchKernelGGL(probe<3>, dim3(grid), dim3(256), 0, 0, d_bad, iters); break;
+      case 3: hipLaunchKernelGGL(probe<3>, dim3(grid), dim3(256), 0, 0, d_bad, iters); break;
+      default: hipLaunchKernelGGL(probe<4>, dim3(grid), dim3(256), 0, 0, d_bad, iters); break;
       }
       CHECK(hipDeviceSynchronize());
       CHECK(hipMemcpy(&h_bad, d_bad, 8, hipMemcpyDeviceToHost));

@@ -300,7 +300,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch the timed steps one by one instead of as one hipGraph")
-    ap.add_argument("--kernel", type=int, default=0, help="0 best, 1 general, 2 LDS-resident, 3 forbidden sets in LDS, 4 forbidden sets in registers")
+    ap.add_argument("--kernel", type=int, default=0, help="0 best, 1 general, 2 LDS-resident, 3 forbidden sets in LDS, 4 forbidden sets in registers, "
+                         "5 = 4 with several nodes per wave (at most 32 variables)")
     ap.add_argument("--rebuild-sets", action="store_true", help="forbidden-set kernel without resident sets")
     ap.add_argument("--layout", choices=["intervals", "sets"], default="intervals",
                     help="intervals: {lo,hi} states with the forbidden sets next to them (default); sets: the states are "
@@ -354,11 +355,13 @@ def main():
     # registers when the model qualifies), 1 general, 2 LDS-resident unit shaving, 3 / 4 forbidden sets
     # in LDS / in registers
     fw = model.forbidden_words()
-    use_sets = fw > 0 and args.kernel in (0, 3, 4) and not args.rebuild_sets
+    use_sets = fw > 0 and args.kernel in (0, 3, 4, 5) and not args.rebuild_sets
     forced = args.kernel
     model.set_kernel(forced)
-    if use_sets or args.kernel in (3, 4):
+    if use_sets or args.kernel in (3, 4, 5):
         kernel_name = "cs_propagate_ne_regs" if (forced in (0, 4) and model.qualifies(4)) else "cs_propagate_ne_bitset"
+        if forced in (0, 5) and model.qualifies(5) and args.layout == "intervals":
+            kernel_name = "cs_propagate_ne_packed"
     else:
         kernel_name = {1: "cs_propagate_events", 2: "cs_propagate_ne_lds"}[model.kernel()]
     n = model.n_vars

@@ -44,7 +44,8 @@ struct csgpu_model {
   cs_tables tab;
   size_t slice;      /* LDS bytes per node instance (16-byte aligned) */
   int has_tree_adj;  /* some adjacency entry is a tree clause */
-  int kernel_choice; /* 0 auto, 1 general, 2 LDS-resident, 3 forbidden sets, 4 forbidden sets in registers */
+  int kernel_choice; /* 0 auto, 1 general, 2 LDS-resident, 3 forbidden sets, 4 forbidden sets in registers, 5 = 4 with
+                        several nodes per wave */
   void *d_adj_packed;
   int lds_waves;     /* waves per workgroup of the LDS-resident kernel, 0 = not eligible */
   size_t lds_bytes;  /* its dynamic LDS size */
@@ -431,6 +432,15 @@ static const void *ne_regs_kernel(int width, int fw, int n_vars, int fast, int s
 #undef CS_PICK_D
 }
 
+/* kernel 5: kernel 4 for small models, 64 / n_vars (2 or 4) nodes per wave */
+static int packed_nodes_per_wave(int fw, int n_vars) { return fw == 1 && n_vars <= 32 ? (n_vars <= 16 ? 4 : 2) : 0; }
+
+static const void *ne_packed_kernel(int width, int n_vars) {
+  if (n_vars <= 16)
+    return width == 1 ? (const void *)cs_propagate_ne_packed<unsigned char, 4> : (const void *)cs_propagate_ne_packed<unsigned short, 4>;
+  return width == 1 ? (const void *)cs_propagate_ne_packed<unsigned char, 2> : (const void *)cs_propagate_ne_packed<unsigned short, 2>;
+}
+
 /* ---- finalize ---------------------------------------------------------------------- */
 
 extern "C" int csgpu_model_build_tables(csgpu_model *m) {
@@ -598,6 +608,9 @@ extern "C" int csgpu_model_finalize(csgpu_model *m) {
           for (int variant = 0; variant < 4; variant++)
             if ((rc = lds_limit(bytes, ne_regs_kernel(m->img->dense_width, m->fb_words, h->n_vars, variant & 1, variant >> 1))))
               return rc;
+          if (packed_nodes_per_wave(m->fb_words, h->n_vars) &&
+              (rc = lds_limit(bytes, ne_packed_kernel(m->img->dense_width, h->n_vars))))
+            return rc;
         }
       }
     }
@@ -625,13 +638,15 @@ extern "C" int csgpu_model_finalize(csgpu_model *m) {
 }
 
 extern "C" int csgpu_model_set_kernel(csgpu_model *m, int which) {
-  if (m == NULL || which < 0 || which > 4) return set_err(CSGPU_E_ARG, "bad argument");
+  if (m == NULL || which < 0 || which > 5) return set_err(CSGPU_E_ARG, "bad argument");
   if (which >= 2) {
     if (!m->finalized) return set_err(CSGPU_E_STATE, "model is not finalized");
     if (which == 2 && !m->lds_waves) return set_err(CSGPU_E_LIMIT, "model does not qualify for the LDS-resident kernel");
     if (which == 3 && !m->fb_words) return set_err(CSGPU_E_LIMIT, "model does not qualify for the forbidden-set kernel");
     if (which == 4 && !m->dense_waves)
       return set_err(CSGPU_E_LIMIT, "model does not qualify for the register-resident forbidden-set kernel");
+    if (which == 5 && !(m->dense_waves && packed_nodes_per_wave(m->fb_words, m->host->n_vars)))
+      return set_err(CSGPU_E_LIMIT, "model does not qualify for the several-nodes-per-wave kernel (at most 32 variables, 64 values)");
   }
   m->kernel_choice = which;
   return CSGPU_OK;
@@ -644,6 +659,7 @@ extern "C" int csgpu_model_qualifies(const csgpu_model *m, int which) {
   case 2: return m->lds_waves != 0;
   case 3: return m->fb_words != 0;
   case 4: return m->dense_waves != 0;
+  case 5: return m->dense_waves != 0 && packed_nodes_per_wave(m->fb_words, m->host->n_vars) != 0;
   default: return 0;
   }
 }
@@ -672,6 +688,16 @@ static int launch_regs(const csgpu_model *m, const csgpu_val *d_states_in, const
   long long nb_d = (long long)batch;
   void *args_d[] = { &n, &tab_d, &slots, &dmin_d, &root_lo_d, &sym_off, &d_states_in, &d_forb_in, &d_nodes,
                      &d_states_out, &d_forb_out, &d_results, &nb_d, &d_batch, &csz, &flags };
+  const int per_wave = sets_only || m->kernel_choice == 4 ? 0 : packed_nodes_per_wave(m->fb_words, n);
+  if (per_wave) { /* kernel 5: one wave per group of nodes, grid-stride */
+    const int64_t groups = (batch + per_wave - 1) / per_wave;
+    int64_t gp = (int64_t)m->n_cus * (int64_t)wgs * 2;
+    const int64_t need_gp = (groups + m->dense_waves - 1) / m->dense_waves;
+    if (gp > need_gp) gp = need_gp;
+    HIP_TRY(hipLaunchKernel(ne_packed_kernel(m->img->dense_width, n), dim3((unsigned)gp),
+                            dim3((unsigned)(m->dense_waves * CS_WAVE)), args_d, m->dense_bytes, (hipStream_t)stream));
+    return CSGPU_OK;
+  }
   const int chunks_v = (n + CS_WAVE - 1) / CS_WAVE;
   const int lanes = (chunks_v <= 1 ? 1 : (chunks_v <= 2 ? 2 : 4)) * CS_WAVE;
   const int fast = n == lanes && d_forb_in != NULL && d_forb_out != NULL && flags == 0;
@@ -850,7 +876,7 @@ extern "C" int csgpu_internal_propagate_obj(const csgpu_model *m, const csgpu_va
     tab.obj_lo = obj_lo;
     tab.obj_hi = obj_hi;
   }
-  if ((m->kernel_choice == 3 || m->kernel_choice == 4) && tab.obj_var < 0)
+  if (m->kernel_choice >= 3 && tab.obj_var < 0)
     return csgpu_internal_propagate_fb(m, d_states_in, NULL, d_nodes, d_states_out, NULL, d_results, batch, d_batch, stream);
   const unsigned long long *bdev = (const unsigned long long *)d_batch;
   if (csgpu_model_get_kernel(m) == 2 && tab.obj_var < 0 && d_batch == NULL) {

@@ -9,6 +9,7 @@
  *   cs_propagate_ne_bitset(3) the same models with forbidden sets per variable in LDS
  *   cs_propagate_ne_regs  (4) models of at most 256 variables: sets and bounds in registers (the bench kernel),
  *                             also with the states carried as the sets alone
+ *   cs_propagate_ne_packed(5) kernel 4 for at most 32 variables: two or four nodes per wave
  *   cs_propagate_sweeps, cs_eval_root, cs_eval_clauses, cs_sets_unpack: root phase, evaluation, layout helper
  *
  * Execution model of the general kernel (cs_propagate_events):
@@ -1321,6 +1322,177 @@ __global__ __launch_bounds__(1024, (FW * R <= 1 ? 8 : 4)) void cs_propagate_ne_r
       }
     }
     if (lane < cnt) results[base + lane] = my_result;
+  }
+}
+
+/* ---- kernel 5: kernel 4 for models of at most 32 variables, G nodes per wave ---------------------
+ *
+ * A model of n <= 64 / G variables with 64-value windows leaves most lanes of kernel 4 idle (queens-16: 16 of
+ * 64).  Here a wave carries G = 2 or 4 nodes at once, node g in lanes g S .. g S + S - 1 (S = 64 / G).  Every
+ * segment runs its own event queue: the ballot of newly valued variables is cut into G segments, each lane
+ * follows the lowest set bit of its own segment, fetches that variable's value with ds_bpermute and reads that
+ * variable's table row.  A segment whose node failed stops pushing; the wave leaves the loop when no segment
+ * has anything left.  Results per node are those of kernel 4 (status, props, revisions, rounds). */
+template <int S>
+__device__ __forceinline__ int cs_segment_sum(int x) { /* valid in the last lane of every S-lane segment */
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true); /* row_shr:1 */
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true); /* row_shr:2 */
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true); /* row_shr:4 */
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true); /* row_shr:8 */
+  if (S == 32) x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, true); /* row_bcast:15 into rows 1 and 3 */
+  return x;
+}
+
+/* this lane's segment of a wave mask (32-bit operations only) */
+template <int G>
+__device__ __forceinline__ unsigned cs_segment_of(unsigned long long mask, int g) {
+  const unsigned lo = (unsigned)mask, hi = (unsigned)(mask >> 32);
+  if (G == 2) return g ? hi : lo;
+  const unsigned h = (g & 2) ? hi : lo;
+  return (g & 1) ? h >> 16 : h & 0xffffu;
+}
+
+template <typename E, int G>
+__global__ __launch_bounds__(1024, 8) void cs_propagate_ne_packed(
+    int n, const E *__restrict__ tab_g, int slots, int dmin, const int *__restrict__ root_lo,
+    const int *__restrict__ sym_off, const cs_val *__restrict__ states_in,
+    const unsigned long long *__restrict__ forb_in, const cs_node_in *__restrict__ nodes,
+    cs_val *__restrict__ states_out, unsigned long long *__restrict__ forb_out, cs_node_out *__restrict__ results,
+    long long batch, const unsigned long long *__restrict__ batch_dev, int csz /* unused */, int flags) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
+  constexpr int S = CS_WAVE / G;
+  constexpr int W = CS_WAVE; /* columns of the table */
+  constexpr unsigned long long SEG = (1ull << S) - 1ull;
+  if (batch_dev != nullptr && (long long)*batch_dev < batch) batch = (long long)*batch_dev;
+  const int lane = threadIdx.x & (CS_WAVE - 1);
+  const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int waves_per_block = blockDim.x >> 6;
+  E *s_tab = (E *)cs_lds;
+  {
+    const int vecs = (int)(((size_t)n * slots * W * sizeof(E)) / 16);
+    const uint4 *src = (const uint4 *)tab_g;
+    uint4 *dst = (uint4 *)cs_lds;
+    for (int i = threadIdx.x; i < vecs; i += blockDim.x) dst[i] = src[i];
+  }
+  __syncthreads();
+
+  const int g = lane / S, v = lane & (S - 1);
+  const bool live = v < n;
+  const int vcl = live ? v : n - 1;
+  const int b0 = live ? root_lo[vcl] : 0;
+  const int deg = live ? sym_off[vcl + 1] - sym_off[vcl] : 0;
+  const bool have_in = forb_in != nullptr;
+  const uint2 *forb_in2 = (const uint2 *)forb_in;
+  uint2 *forb_out2 = (uint2 *)forb_out;
+
+  const long long groups = (batch + G - 1) / G;
+  const long long waves_total = (long long)gridDim.x * waves_per_block;
+  long long q = (long long)blockIdx.x * waves_per_block + wave_in_block;
+  if (q >= groups) return;
+
+  /* one group of G nodes ahead; a node past the end of the batch re-reads the last node and stores nothing */
+  cs_node_in rec_n;
+  cs_val pd_n;
+  uint2 pf_n;
+  {
+    const long long node = q * G + g < batch ? q * G + g : batch - 1;
+    rec_n = nodes[node];
+    const size_t prow = (size_t)rec_n.parent * n + vcl;
+    pd_n = states_in[prow];
+    pf_n = have_in ? forb_in2[prow] : make_uint2(0u, 0u);
+  }
+  for (; q < groups; q += waves_total) {
+    const long long node = q * G + g;
+    const bool valid = node < batch;
+    const int nvar = rec_n.var, nlo = rec_n.lo, nhi = rec_n.hi;
+    int lo = live ? pd_n.lo : 0, hi = live ? pd_n.hi : 0;
+    unsigned fb[2]; /* a lane without a variable behaves like a variable fixed at its window's first value */
+    fb[0] = live ? pf_n.x : 0xfffffffeu;
+    fb[1] = live ? pf_n.y : 0xffffffffu;
+    {
+      const long long qn = q + waves_total < groups ? q + waves_total : q;
+      const long long nn = qn * G + g < batch ? qn * G + g : batch - 1;
+      rec_n = nodes[nn];
+      const size_t prow = (size_t)rec_n.parent * n + vcl;
+      pd_n = states_in[prow];
+      pf_n = have_in ? forb_in2[prow] : make_uint2(0u, 0u);
+    }
+
+    /* the assignment (step_enter, csolve.c:294-304) and the first variables to push */
+    const bool mine = nvar >= 0 && v == nvar;
+    if ((flags & CS_K4_OUT_RESTRICT) && mine) cs_set_restrict<2>(fb, nlo - b0, nhi - b0);
+    if (mine) { lo = nlo; hi = nhi; }
+    bool pushme = live && lo == hi && (!have_in || nvar < 0 || mine);
+    const int lo0 = lo, hi0 = hi;
+    int rounds = 0, myrev = 0;
+    bool failed = false;
+    for (;;) {
+      /* (1) newly valued variables push their forbidden value into the sets of their own node */
+      unsigned long long pm = __ballot(pushme);
+      myrev += pushme ? deg : 0;
+      while (pm != 0ull) {
+        const unsigned seg = cs_segment_of<G>(pm, g);
+        const bool act = seg != 0u;
+        const int ul = act ? __builtin_ctz(seg) : 0;
+        {
+          unsigned long long rest = 0ull; /* every segment drops its lowest bit (scalar) */
+#pragma unroll
+          for (int gg = 0; gg < G; gg++) {
+            unsigned long long sg = (pm >> (gg * S)) & SEG;
+            sg &= sg - 1ull;
+            rest |= sg << (gg * S);
+          }
+          pm = rest;
+        }
+        int cd = __builtin_amdgcn_ds_bpermute(((lane & ~(S - 1)) + ul) << 2, lo) - dmin;
+        cd = act ? cd : 0x40000000; /* selects no word below */
+        const E *row = s_tab + (size_t)ul * slots * W + v;
+        for (int k0 = 0; k0 < slots; k0 += 3) {
+          const int k1 = k0 + 1 < slots ? k0 + 1 : slots - 1, k2 = k0 + 2 < slots ? k0 + 2 : slots - 1;
+          E e[3];
+          e[0] = row[k0 * W];
+          e[1] = row[k1 * W];
+          e[2] = row[k2 * W];
+#pragma unroll
+          for (int t = 0; t < 3; t++) {
+            const unsigned bit = (unsigned)(cd - (int)e[t]);
+            const unsigned sel = bit >> 5, m = 1u << (bit & 31u);
+            fb[0] |= sel == 0u ? m : 0u;
+            fb[1] |= sel == 1u ? m : 0u;
+          }
+        }
+      }
+      /* (2) bounds from the sets */
+      int first, last;
+      cs_set_bounds<2>(fb, lo - b0, hi - b0, &first, &last);
+      const bool bad = last < 0;
+      const int nlo2 = b0 + first, nhi2 = b0 + last;
+      const bool newly = !bad && (nlo2 != lo || nhi2 != hi) && nlo2 == nhi2;
+      lo = bad ? lo : nlo2;
+      hi = bad ? hi : nhi2;
+      failed = failed || cs_segment_of<G>(__ballot(bad), g) != 0u;
+      pushme = newly && !failed;
+      const unsigned long long am = __ballot(pushme);
+      if (am == 0ull) break;
+      rounds += cs_segment_of<G>(am, g) != 0u ? 1 : 0;
+    }
+
+    const int open_vars = __popc(cs_segment_of<G>(__ballot(lo != hi), g));
+    const int props = cs_segment_sum<S>((lo - lo0) + (hi0 - hi));
+    const int revisions = cs_segment_sum<S>(myrev);
+    if (flags & CS_K4_OUT_RESTRICT) cs_set_restrict<2>(fb, lo - b0, hi - b0);
+    const bool st = valid && live && !failed;
+    const size_t orow = (size_t)node * n + v;
+    if (st && states_out != nullptr) states_out[orow] = cs_interval(lo, hi);
+    if (st && forb_out != nullptr) forb_out2[orow] = make_uint2(fb[0], fb[1]);
+    if (valid && v == S - 1) {
+      cs_node_out r;
+      r.status = failed ? -1 : open_vars;
+      r.props = props;
+      r.revisions = revisions;
+      r.rounds = rounds;
+      results[node] = r;
+    }
   }
 }
 

@@ -27,6 +27,8 @@ def _kernels(model):
         ks.append(3)  # forbidden-set kernel, sets rebuilt from the incoming state
     if model.qualifies(4):
         ks.append(4)  # the same with the sets in registers
+    if model.qualifies(5):
+        ks.append(5)  # several nodes per wave (at most 32 variables)
     return ks
 
 
@@ -230,7 +232,8 @@ def test_propagate_one_host_path():
 
 @pytest.mark.parametrize("kind,size,kernel", [("queens", 16, 3), ("queens", 64, 3), ("queens", 128, 3), ("sudoku", 3, 3),
                                               ("sudoku", 5, 3), ("queens", 16, 4), ("queens", 64, 4), ("queens", 128, 4),
-                                              ("queens", 100, 4), ("sudoku", 3, 4), ("sudoku", 4, 4)])
+                                              ("queens", 100, 4), ("sudoku", 3, 4), ("sudoku", 4, 4),
+                                              ("queens", 16, 5), ("queens", 13, 5), ("queens", 17, 5), ("queens", 32, 5)])
 def test_forbidden_sets_inherited_down_a_path(kind, size, kernel):
     """The forbidden-set kernel with the sets carried from parent to child (the search engine's
     mode) against the general kernel and the oracle, five levels deep: same verdicts, same
@@ -242,7 +245,7 @@ def test_forbidden_sets_inherited_down_a_path(kind, size, kernel):
     model = solve_root(text)
     fw = model.forbidden_words()
     assert fw > 0
-    model.set_kernel(kernel)  # 3: sets in LDS, 4: sets in registers
+    model.set_kernel(kernel)  # 3: sets in LDS, 4: sets in registers, 5: in registers, 2 or 4 nodes per wave
     n = model.n_vars
     omodel = OModel.parse(text)
     omodel.set_domains(model.domains())
@@ -291,11 +294,12 @@ def test_forbidden_sets_inherited_down_a_path(kind, size, kernel):
 
 
 @pytest.mark.parametrize("kind,size,count", [("queens", 64, 1 << 17), ("queens", 128, 1 << 16), ("queens", 100, 1 << 15),
-                                             ("sudoku", 4, 1 << 15), ("sudoku", 3, 1 << 15)])
+                                             ("sudoku", 4, 1 << 15), ("sudoku", 3, 1 << 15),
+                                             ("queens", 16, (1 << 17) + 3), ("queens", 30, (1 << 16) + 1)])
 def test_large_batches_agree_across_kernels(kind, size, count):
     """Batches large enough that every wave walks through several chunks of nodes under full load
     (the small parity batches give each wave at most one chunk): the forbidden-set kernels with
-    resident sets (3: LDS, 4: registers, where the model qualifies) against the general kernel on
+    resident sets (3: LDS, 4: registers, 5: several nodes per wave, where the model qualifies) against the general kernel on
     every node -- verdict, fixpoint, PROPS -- and against each other on the carried sets, over
     repeated launches (a timing-dependent fault shows up as a difference between launches)."""
     import bench
@@ -311,7 +315,7 @@ def test_large_batches_agree_across_kernels(kind, size, count):
     ok = r1[:, 0] >= 0
     assert 0 < int(ok.sum()) < count
     sets = {}
-    for k in (3, 4):
+    for k in (3, 4, 5):
         if not model.qualifies(k):
             continue
         model.set_kernel(k)
@@ -324,8 +328,8 @@ def test_large_batches_agree_across_kernels(kind, size, count):
             if k in sets:
                 assert torch.equal(f[ok], sets[k]), (k, launch)
             sets[k] = f[ok]
-    if len(sets) == 2:
-        assert torch.equal(sets[3], sets[4])
+    for k in sets:
+        assert torch.equal(sets[3], sets[k]), k
 
 
 @pytest.mark.parametrize("name", ["ref_schedule", "schedule6_s1", "ref_wcet"])

@@ -238,7 +238,8 @@ def search_workload(args, rank, world, local, dist):
     n = model.n_vars
     comm = "cpu" if args.comm == "gloo" else "cuda"
 
-    eng = Search(model, args.pool, args.children)  # buffers are allocated once, outside the timed region
+    max_children = args.children or (1 << 21 if n <= 32 else 1 << 19)
+    eng = Search(model, args.pool or 8 * max_children, max_children)  # buffers are allocated once, outside the timed region
 
     def once():
         eng.reset()
@@ -311,8 +312,9 @@ def main():
     ap.add_argument("--search-objective", choices=["ALL", "ANY"], default="ALL")
     ap.add_argument("--search-schedule", type=int, default=0, help="search workload on a schedule.txt-style MIN model of this "
                     "many tasks instead of queens (BASELINE configs[4] shape: the incumbent bound travels between the ranks)")
-    ap.add_argument("--pool", type=int, default=1 << 22)
-    ap.add_argument("--children", type=int, default=1 << 19)
+    ap.add_argument("--pool", type=int, default=0, help="search workload: rows of the state pool (default: 8 x --children)")
+    ap.add_argument("--children", type=int, default=0, help="search workload: children per iteration at most "
+                    "(default: 2^21 for models of at most 32 variables, else 2^19)")
     ap.add_argument("--slice", type=int, default=32, help="search iterations between rank exchanges")
     ap.add_argument("--search-slices", type=int, default=0,
                     help="stop a search after this many slices (0 = run to the end): ALL on trees too large to finish")

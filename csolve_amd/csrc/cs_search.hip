@@ -34,7 +34,7 @@ struct csgpu_search {
   int fw;
   unsigned long long *pool_forb, *d_child_forb;
   csgpu_node *d_rebuild_nodes;
-  int *d_branch_var, *d_child_count, *d_child_off;
+  int *d_branch_var, *d_child_count, *d_child_off /* per workgroup of cs_branch */, *d_block_sum;
   csgpu_node *d_nodes;
   cs_val *d_child_states, *d_complete_states;
   csgpu_result *d_results;
@@ -65,14 +65,15 @@ static int flush_accept_results(csgpu_search *s);
     if (e_ != hipSuccess) return fail(CSGPU_E_HIP, hipGetErrorString(e_));     \
   } while (0)
 
-/* one wave per parent: the open variable with the smallest interval (ties: lowest index), the
- * reference's "-o smallest-domain" idea (strategy.c:85-91) as a pure function of the state.
- * Intervals wider than SPLIT_WIDTH are halved (two children) instead of enumerated.
- * -> var (-1: no open variable) and the number of children, in every lane */
-__device__ __forceinline__ void cs_branch_wave(const cs_val *__restrict__ row, int n, int lane, int *var, int *count) {
-  /* key = (width-1) * 2^32 + index, minimised over the wave */
+/* S lanes (a whole wave, or a half or a quarter of one for small models) per parent: the open variable with
+ * the smallest interval (ties: lowest index), the reference's "-o smallest-domain" idea (strategy.c:85-91) as a
+ * pure function of the state.  Intervals wider than SPLIT_WIDTH are halved (two children) instead of enumerated.
+ * -> var (-1: no open variable) and the number of children, in every lane of the segment */
+template <int S>
+__device__ __forceinline__ void cs_branch_seg(const cs_val *__restrict__ row, int n, int sl, int *var, int *count) {
+  /* key = (width-1) * 2^32 + index, minimised over the segment */
   unsigned long long best = ~0ull;
-  for (int v = lane; v < n; v += 64) {
+  for (int v = sl; v < n; v += S) {
     const cs_val d = row[v];
     if (d.lo != d.hi) {
       const unsigned long long w = (unsigned long long)((long long)d.hi - (long long)d.lo);
@@ -80,7 +81,7 @@ __device__ __forceinline__ void cs_branch_wave(const cs_val *__restrict__ row, i
       best = key < best ? key : best;
     }
   }
-  for (int o = 32; o > 0; o >>= 1) {
+  for (int o = S / 2; o > 0; o >>= 1) {
     const unsigned long long other = __shfl_xor(best, o);
     best = other < best ? other : best;
   }
@@ -94,16 +95,31 @@ __device__ __forceinline__ void cs_branch_wave(const cs_val *__restrict__ row, i
   }
 }
 
+/* a workgroup takes SB / S consecutive parents; besides var and count per parent it leaves the number of
+ * children of its parents in block_sum, so that the scan that follows runs over workgroups, not parents */
+template <int S>
 __global__ __launch_bounds__(SB) void cs_branch(const cs_val *__restrict__ pool, long long first_row, int parents,
-                                                int n, int *__restrict__ branch_var, int *__restrict__ child_count) {
-  const int lane = threadIdx.x & 63;
-  const int p = blockIdx.x * (SB / 64) + (threadIdx.x >> 6);
-  if (p >= parents) return;
+                                                int n, int *__restrict__ branch_var, int *__restrict__ child_count,
+                                                int *__restrict__ block_sum) {
+  constexpr int PPB = SB / S;
+  __shared__ int s_cnt[PPB];
+  const int seg = threadIdx.x / S, sl = threadIdx.x & (S - 1);
+  const int p = blockIdx.x * PPB + seg;
+  const int pc = p < parents ? p : parents - 1; /* segments past the end redo the last parent and drop it */
   int var, count;
-  cs_branch_wave(pool + (size_t)(first_row + p) * n, n, lane, &var, &count);
-  if (lane == 0) {
-    branch_var[p] = var;
-    child_count[p] = count;
+  cs_branch_seg<S>(pool + (size_t)(first_row + pc) * n, n, sl, &var, &count);
+  if (sl == 0) {
+    if (p < parents) {
+      branch_var[p] = var;
+      child_count[p] = count;
+    }
+    s_cnt[seg] = p < parents ? count : 0;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int total = 0;
+    for (int i = 0; i < PPB; i++) total += s_cnt[i];
+    block_sum[blockIdx.x] = total;
   }
 }
 
@@ -173,65 +189,80 @@ __global__ __launch_bounds__(1024) void cs_scan(const int *__restrict__ count, i
 }
 
 /* the per-block class counts of cs_classify_count: exclusive scans of the survivors and of the complete
- * children, sums of cuts / propagations / revisions -> counters */
+ * children (one scan: survivors in the low half of a 64-bit word, complete children in the high half), sums
+ * of cuts / propagations / revisions -> counters */
 __global__ __launch_bounds__(1024) void cs_scan_classes(const int *__restrict__ block_surv, const int *__restrict__ block_comp,
                                                         const int *__restrict__ block_cuts, const int *__restrict__ block_props,
                                                         const int *__restrict__ block_revs, int blocks,
                                                         int *__restrict__ surv_off, int *__restrict__ comp_off,
                                                         unsigned long long *__restrict__ counters) {
   __shared__ long long s_part[16];
-  long long carry_s = 0, carry_c = 0, cuts = 0, props = 0, revs = 0;
-  for (int base = 0; base < blocks; base += 1024) {
-    const int i = base + (int)threadIdx.x;
-    const bool in = i < blocks;
+  constexpr int PER = 4;
+  long long carry = 0, cuts = 0, props = 0, revs = 0;
+  for (int base = 0; base < blocks; base += 1024 * PER) {
+    const int first = base + (int)threadIdx.x * PER;
+    long long x[PER], sum = 0;
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+      const int i = first + q;
+      const bool in = i < blocks;
+      const long long v = in ? (long long)block_surv[i] | ((long long)block_comp[i] << 32) : 0;
+      x[q] = sum;
+      sum += v;
+      cuts += in ? block_cuts[i] : 0;
+      props += in ? block_props[i] : 0;
+      revs += in ? block_revs[i] : 0;
+    }
     long long total;
-    const long long es = cs_block_excl_scan(in ? block_surv[i] : 0, s_part, &total);
-    if (in) surv_off[i] = (int)(carry_s + es);
-    carry_s += total;
-    const long long ec = cs_block_excl_scan(in ? block_comp[i] : 0, s_part, &total);
-    if (in) comp_off[i] = (int)(carry_c + ec);
-    carry_c += total;
-    (void)cs_block_excl_scan(in ? block_cuts[i] : 0, s_part, &total);
-    cuts += total;
-    (void)cs_block_excl_scan(in ? block_props[i] : 0, s_part, &total);
-    props += total;
-    (void)cs_block_excl_scan(in ? block_revs[i] : 0, s_part, &total);
-    revs += total;
+    const long long ex = carry + cs_block_excl_scan(sum, s_part, &total);
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+      const int i = first + q;
+      if (i < blocks) {
+        surv_off[i] = (int)((ex + x[q]) & 0xffffffffll);
+        comp_off[i] = (int)((ex + x[q]) >> 32);
+      }
+    }
+    carry += total;
   }
+  long long t_cuts, t_props, t_revs;
+  (void)cs_block_excl_scan(cuts, s_part, &t_cuts);
+  (void)cs_block_excl_scan(props, s_part, &t_props);
+  (void)cs_block_excl_scan(revs, s_part, &t_revs);
   if (threadIdx.x == 0) {
-    surv_off[blocks] = (int)carry_s;
-    comp_off[blocks] = (int)carry_c;
-    counters[C_SURVIVORS] = (unsigned long long)carry_s;
-    counters[C_COMPLETE] = (unsigned long long)carry_c;
-    counters[C_CUTS] = (unsigned long long)cuts;
-    counters[C_PROPS] = (unsigned long long)props;
-    counters[C_REVS] = (unsigned long long)revs;
+    surv_off[blocks] = (int)(carry & 0xffffffffll);
+    comp_off[blocks] = (int)(carry >> 32);
+    counters[C_SURVIVORS] = (unsigned long long)(carry & 0xffffffffll);
+    counters[C_COMPLETE] = (unsigned long long)(carry >> 32);
+    counters[C_CUTS] = (unsigned long long)t_cuts;
+    counters[C_PROPS] = (unsigned long long)t_props;
+    counters[C_REVS] = (unsigned long long)t_revs;
   }
 }
 
-/* one wave per parent writes its children {var, value, value, parent_row} */
-/* one wave writes the children {var, value, value, parent_row} of one parent at nodes[beg, beg + cnt) */
-__device__ __forceinline__ void cs_emit_wave(const cs_val *__restrict__ pool, long long row, int n, int var, int beg, int cnt,
-                                             csgpu_node *__restrict__ nodes, int low_values_last, unsigned scramble,
-                                             int lane) {
+/* S lanes write the children {var, value, value, parent_row} of one parent at nodes[beg, beg + cnt) */
+template <int S>
+__device__ __forceinline__ void cs_emit_seg(const cs_val *__restrict__ pool, long long row, int n, int var, int beg, int cnt,
+                                            csgpu_node *__restrict__ nodes, int low_values_last, unsigned scramble,
+                                            int sl) {
   if (var < 0) return;
   const cs_val d = pool[(size_t)row * n + var];
   const long long width = (long long)d.hi - (long long)d.lo + 1;
   if (width > SPLIT_WIDTH) { /* two halves, lower half first */
     const int mid = (int)(((long long)d.lo + (long long)d.hi) >> 1);
-    if (lane < 2) {
+    if (sl < 2) {
       /* the pool is LIFO and later children land higher: the half written last is explored first */
-      const int lower = low_values_last ? lane == 1 : lane == 0;
+      const int lower = low_values_last ? sl == 1 : sl == 0;
       csgpu_node nd;
       nd.var = var;
       nd.lo = lower ? d.lo : mid + 1;
       nd.hi = lower ? mid : d.hi;
       nd.parent = (int)row;
-      nodes[beg + lane] = nd;
+      nodes[beg + sl] = nd;
     }
     return;
   }
-  for (int k = lane; k < cnt; k += 64) {
+  for (int k = sl; k < cnt; k += S) {
     csgpu_node nd;
     int value = low_values_last ? d.hi - k : d.lo + k;
     if (scramble != 0u) {
@@ -250,15 +281,20 @@ __device__ __forceinline__ void cs_emit_wave(const cs_val *__restrict__ pool, lo
   }
 }
 
+/* same geometry as cs_branch<S>: block_off[b] = children before this workgroup's parents (the scan of
+ * cs_branch's block sums), the few parents in front within the workgroup are added up directly */
+template <int S>
 __global__ __launch_bounds__(SB) void cs_emit(const cs_val *__restrict__ pool, long long first_row, int parents, int n,
-                                              const int *__restrict__ branch_var, const int *__restrict__ child_off,
-                                              csgpu_node *__restrict__ nodes, int low_values_last,
-                                              unsigned scramble) {
-  const int lane = threadIdx.x & 63;
-  const int p = blockIdx.x * (SB / 64) + (threadIdx.x >> 6);
+                                              const int *__restrict__ branch_var, const int *__restrict__ child_count,
+                                              const int *__restrict__ block_off, csgpu_node *__restrict__ nodes,
+                                              int low_values_last, unsigned scramble) {
+  constexpr int PPB = SB / S;
+  const int seg = threadIdx.x / S, sl = threadIdx.x & (S - 1);
+  const int p = blockIdx.x * PPB + seg;
   if (p >= parents) return;
-  cs_emit_wave(pool, first_row + p, n, branch_var[p], child_off[p], child_off[p + 1] - child_off[p], nodes,
-               low_values_last, scramble, lane);
+  int beg = block_off[blockIdx.x];
+  for (int j = blockIdx.x * PPB; j < p; j++) beg += child_count[j];
+  cs_emit_seg<S>(pool, first_row + p, n, branch_var[p], beg, child_count[p], nodes, low_values_last, scramble, sl);
 }
 
 /* ---- small iterations (at most SMALL_PARENTS parents: always for ANY / MIN / MAX): one workgroup does what
@@ -275,7 +311,7 @@ __global__ __launch_bounds__(1024) void cs_expand_small(const cs_val *__restrict
   if (threadIdx.x < C_PER_ITERATION) counters[threadIdx.x] = 0ull;
   for (int p = wave; p < parents; p += 16) {
     int var, count;
-    cs_branch_wave(pool + (size_t)(first_row + p) * n, n, lane, &var, &count);
+    cs_branch_seg<64>(pool + (size_t)(first_row + p) * n, n, lane, &var, &count);
     if (lane == 0) { s_var[p] = var; s_cnt[p] = count; }
   }
   __syncthreads();
@@ -286,7 +322,7 @@ __global__ __launch_bounds__(1024) void cs_expand_small(const cs_val *__restrict
   if (t == 0) counters[C_TOTAL_CHILDREN] = (unsigned long long)total;
   __syncthreads();
   for (int p = wave; p < parents; p += 16)
-    cs_emit_wave(pool, first_row + p, n, s_var[p], s_off[p], s_cnt[p], nodes, low_values_last, scramble, lane);
+    cs_emit_seg<64>(pool, first_row + p, n, s_var[p], s_off[p], s_cnt[p], nodes, low_values_last, scramble, lane);
 }
 
 
@@ -389,25 +425,35 @@ __global__ __launch_bounds__(1024) void cs_classify_small(const csgpu_result *__
   }
 }
 
-/* one wave per child: copy survivors into their pool rows */
+/* copy survivors into their pool rows: a workgroup takes cpb (at most SB) consecutive children and walks their
+ * cpb * n elements flat, so that small models fill the lanes too (dest < 0: not a survivor) */
 __global__ __launch_bounds__(SB) void cs_scatter(const cs_val *__restrict__ child_states, const int *__restrict__ dest,
                                                  int children, int n, cs_val *__restrict__ pool,
                                                  const unsigned long long *__restrict__ child_forb,
                                                  unsigned long long *__restrict__ pool_forb, int fw,
-                                                 const unsigned long long *__restrict__ children_dev) {
-  const int lane = threadIdx.x & 63;
-  const int i = blockIdx.x * (SB / 64) + (threadIdx.x >> 6);
+                                                 const unsigned long long *__restrict__ children_dev, int cpb) {
+  __shared__ int s_dest[SB];
   if (children_dev != nullptr && (unsigned long long)children > *children_dev) children = (int)*children_dev;
-  if (i >= children) return;
-  const int d = dest[i];
-  if (d < 0) return;
-  const cs_val *src = child_states + (size_t)i * n;
-  cs_val *dst = pool + (size_t)d * n;
-  for (int v = lane; v < n; v += 64) dst[v] = src[v];
+  const long long base = (long long)blockIdx.x * cpb;
+  if (base >= children) return;
+  const int here = children - base < cpb ? (int)(children - base) : cpb;
+  if ((int)threadIdx.x < here) s_dest[threadIdx.x] = dest[base + threadIdx.x];
+  __syncthreads();
+  const unsigned total = (unsigned)here * (unsigned)n;
+  const cs_val *src = child_states + (size_t)base * n;
+  for (unsigned e = threadIdx.x; e < total; e += SB) {
+    const unsigned c = e / (unsigned)n, v = e - c * (unsigned)n;
+    const int d = s_dest[c];
+    if (d >= 0) pool[(size_t)d * n + v] = src[e];
+  }
   if (fw > 0) {
-    const unsigned long long *fs = child_forb + (size_t)i * n * fw;
-    unsigned long long *fd = pool_forb + (size_t)d * n * fw;
-    for (int k = lane; k < n * fw; k += 64) fd[k] = fs[k];
+    const unsigned long long *fs = child_forb + (size_t)base * n * fw;
+    const unsigned nf = (unsigned)n * (unsigned)fw, total_f = (unsigned)here * nf;
+    for (unsigned e = threadIdx.x; e < total_f; e += SB) {
+      const unsigned c = e / nf, k = e - c * nf;
+      const int d = s_dest[c];
+      if (d >= 0) pool_forb[(size_t)d * nf + k] = fs[e];
+    }
   }
 }
 
@@ -511,7 +557,7 @@ __global__ __launch_bounds__(SB) void cs_move_rows(unsigned long long *__restric
 extern "C" void csgpu_search_free(csgpu_search *s) {
   if (s == NULL) return;
   (void)hipFree(s->pool_forb); (void)hipFree(s->d_child_forb); (void)hipFree(s->d_rebuild_nodes);
-  (void)hipFree(s->pool); (void)hipFree(s->d_branch_var); (void)hipFree(s->d_child_count); (void)hipFree(s->d_child_off);
+  (void)hipFree(s->pool); (void)hipFree(s->d_branch_var); (void)hipFree(s->d_child_count); (void)hipFree(s->d_child_off); (void)hipFree(s->d_block_sum);
   (void)hipFree(s->d_nodes); (void)hipFree(s->d_child_states); (void)hipFree(s->d_complete_states);
   (void)hipFree(s->d_results); (void)hipFree(s->d_dest); (void)hipFree(s->d_complete_list); (void)hipFree(s->d_truth);
   (void)hipFree(s->d_block_surv); (void)hipFree(s->d_block_comp); (void)hipFree(s->d_surv_off); (void)hipFree(s->d_comp_off);
@@ -581,6 +627,7 @@ extern "C" int csgpu_search_create(const csgpu_model *m, int64_t pool_capacity, 
   ALLOC(s->d_branch_var, sizeof(int) * (size_t)max_children);
   ALLOC(s->d_child_count, sizeof(int) * (size_t)max_children);
   ALLOC(s->d_child_off, sizeof(int) * ((size_t)max_children + 1));
+  ALLOC(s->d_block_sum, sizeof(int) * ((size_t)max_children + 1));
   ALLOC(s->d_nodes, sizeof(csgpu_node) * (size_t)max_children);
   ALLOC(s->d_child_states, row * (size_t)max_children);
   ALLOC(s->d_complete_states, row * (size_t)max_children);
@@ -800,11 +847,20 @@ static int one_iteration(csgpu_search *s) {
     HIP_OK(hipMemsetAsync(s->d_counters, 0, sizeof(unsigned long long) * C_PER_ITERATION, 0));
     unsigned pb;
     for (;;) {
-      pb = (unsigned)((parents + 3) / 4);
-      hipLaunchKernelGGL(cs_branch, dim3(pb), dim3(SB), 0, 0, s->pool, first_row, (int)parents, n, s->d_branch_var,
-                         s->d_child_count);
-      hipLaunchKernelGGL(cs_scan, dim3(1), dim3(1024), 0, 0, s->d_child_count, (int)parents, s->d_child_off,
-                         s->d_counters, (int)C_TOTAL_CHILDREN);
+      /* 16, 32 or 64 lanes per parent */
+      const int ppb = n <= 16 ? SB / 16 : (n <= 32 ? SB / 32 : SB / 64);
+      pb = (unsigned)((parents + ppb - 1) / ppb);
+      if (n <= 16)
+        hipLaunchKernelGGL(cs_branch<16>, dim3(pb), dim3(SB), 0, 0, s->pool, first_row, (int)parents, n, s->d_branch_var,
+                           s->d_child_count, s->d_block_sum);
+      else if (n <= 32)
+        hipLaunchKernelGGL(cs_branch<32>, dim3(pb), dim3(SB), 0, 0, s->pool, first_row, (int)parents, n, s->d_branch_var,
+                           s->d_child_count, s->d_block_sum);
+      else
+        hipLaunchKernelGGL(cs_branch<64>, dim3(pb), dim3(SB), 0, 0, s->pool, first_row, (int)parents, n, s->d_branch_var,
+                           s->d_child_count, s->d_block_sum);
+      hipLaunchKernelGGL(cs_scan, dim3(1), dim3(1024), 0, 0, s->d_block_sum, (int)pb, s->d_child_off, s->d_counters,
+                         (int)C_TOTAL_CHILDREN);
       /* first host read of the iteration: the number of children, and with it what the previous
        * iteration's accept left behind (solutions so far, incumbent) */
       unsigned long long head[C_COUNT - C_TOTAL_CHILDREN];
@@ -823,8 +879,15 @@ static int one_iteration(csgpu_search *s) {
     }
     d_children = NULL;
     if (children > s->max_children) return fail(CSGPU_E_LIMIT, "internal: more children than the batch buffers hold");
-    hipLaunchKernelGGL(cs_emit, dim3(pb), dim3(SB), 0, 0, s->pool, first_row, (int)parents, n, s->d_branch_var,
-                       s->d_child_off, s->d_nodes, low_last, scramble);
+    if (n <= 16)
+      hipLaunchKernelGGL(cs_emit<16>, dim3(pb), dim3(SB), 0, 0, s->pool, first_row, (int)parents, n, s->d_branch_var,
+                         s->d_child_count, s->d_child_off, s->d_nodes, low_last, scramble);
+    else if (n <= 32)
+      hipLaunchKernelGGL(cs_emit<32>, dim3(pb), dim3(SB), 0, 0, s->pool, first_row, (int)parents, n, s->d_branch_var,
+                         s->d_child_count, s->d_child_off, s->d_nodes, low_last, scramble);
+    else
+      hipLaunchKernelGGL(cs_emit<64>, dim3(pb), dim3(SB), 0, 0, s->pool, first_row, (int)parents, n, s->d_branch_var,
+                         s->d_child_count, s->d_child_off, s->d_nodes, low_last, scramble);
     /* the incumbent may just have improved */
     if (s->objective == CS_OBJ_MIN) obj_hi = cs_add(s->st.best, cs_neg(1));
     if (s->objective == CS_OBJ_MAX) obj_lo = cs_add(s->st.best, 1);
@@ -842,7 +905,7 @@ static int one_iteration(csgpu_search *s) {
     rc = csgpu_internal_propagate_obj(s->m, (const csgpu_val *)s->pool, s->d_nodes, (csgpu_val *)s->d_child_states,
                                       s->d_results, children, d_children, obj_lo, obj_hi, NULL);
   if (rc != CSGPU_OK) return rc;
-  const unsigned cb = (unsigned)((children + SB - 1) / SB), cw = (unsigned)((children + 3) / 4);
+  const unsigned cb = (unsigned)((children + SB - 1) / SB);
   if (small) {
     hipLaunchKernelGGL(cs_classify_small, dim3(1), dim3(1024), 0, 0, s->d_results, (long long)s->top, s->d_dest,
                        s->d_complete_list, s->d_counters);
@@ -854,8 +917,15 @@ static int one_iteration(csgpu_search *s) {
     hipLaunchKernelGGL(cs_classify_assign, dim3(cb), dim3(SB), 0, 0, s->d_results, (int)children, (long long)s->top,
                        s->d_surv_off, s->d_comp_off, s->d_dest, s->d_complete_list);
   }
-  hipLaunchKernelGGL(cs_scatter, dim3(cw), dim3(SB), 0, 0, s->d_child_states, s->d_dest, (int)children, n, s->pool,
-                     s->d_child_forb, s->pool_forb, s->fw, (const unsigned long long *)d_children);
+  {
+    /* about 4096 state elements per workgroup, fewer when that would leave most of the machine idle */
+    int cpb = 4096 / n;
+    cpb = cpb < 4 ? 4 : (cpb > SB ? SB : cpb);
+    while (cpb > 4 && children / cpb < 2048) cpb >>= 1;
+    hipLaunchKernelGGL(cs_scatter, dim3((unsigned)((children + cpb - 1) / cpb)), dim3(SB), 0, 0, s->d_child_states, s->d_dest,
+                       (int)children, n, s->pool, s->d_child_forb, s->pool_forb, s->fw,
+                       (const unsigned long long *)d_children, cpb);
+  }
   /* the (only, for a small iteration) host read: class counts, the real number of children, and what the
    * previous iteration's accept left behind */
   unsigned long long c[C_COUNT];

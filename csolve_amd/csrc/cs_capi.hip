@@ -44,6 +44,8 @@ struct csgpu_model {
   cs_tables tab;
   size_t slice;      /* LDS bytes per node instance (16-byte aligned) */
   int has_tree_adj;  /* some adjacency entry is a tree clause */
+  int packed_bias;   /* kernel 5: largest root_lo - dense_dmin */
+  int packed_nw;     /* kernel 5: set words per variable it works on (1: all root domains within 32 values) */
   int kernel_choice; /* 0 auto, 1 general, 2 LDS-resident, 3 forbidden sets, 4 forbidden sets in registers, 5 = 4 with
                         several nodes per wave */
   void *d_adj_packed;
@@ -56,6 +58,7 @@ struct csgpu_model {
   int dense_waves;    /* register-resident forbidden-set kernel: waves per workgroup, 0 = not eligible */
   size_t dense_bytes; /* its LDS table */
   void *d_dense_tab;
+  void *d_packed_tab; /* kernel 5: 16-bit table relative to the pushing variable */
   int *d_root_lo;
   int *d_sym_off;
   void *d_sym_packed;
@@ -152,6 +155,8 @@ static void free_device(csgpu_model *m) {
   (void)hipFree(m->d_sym_off);
   (void)hipFree(m->d_sym_packed);
   (void)hipFree(m->d_dense_tab);
+  (void)hipFree(m->d_packed_tab);
+  m->d_packed_tab = NULL;
   m->d_sym_off = NULL;
   m->d_sym_packed = NULL;
   m->d_dense_tab = NULL;
@@ -432,13 +437,22 @@ static const void *ne_regs_kernel(int width, int fw, int n_vars, int fast, int s
 #undef CS_PICK_D
 }
 
-/* kernel 5: kernel 4 for small models, 64 / n_vars (2 or 4) nodes per wave */
-static int packed_nodes_per_wave(int fw, int n_vars) { return fw == 1 && n_vars <= 32 ? (n_vars <= 16 ? 4 : 2) : 0; }
+/* kernel 5: kernel 4 for small models, 64 / n_vars (2 or 4) nodes per wave; needs the 8-bit dense table (its
+ * 16-bit LDS copy is relative to the pushing variable, cs_kernels.hip.h) */
+static int packed_nodes_per_wave(int fw, int n_vars, int dense_width) {
+  return fw == 1 && dense_width == 1 && n_vars <= 32 ? (n_vars <= 16 ? 4 : 2) : 0;
+}
 
-static const void *ne_packed_kernel(int width, int n_vars) {
-  if (n_vars <= 16)
-    return width == 1 ? (const void *)cs_propagate_ne_packed<unsigned char, 4> : (const void *)cs_propagate_ne_packed<unsigned short, 4>;
-  return width == 1 ? (const void *)cs_propagate_ne_packed<unsigned char, 2> : (const void *)cs_propagate_ne_packed<unsigned short, 2>;
+static const void *ne_packed_kernel(int n_vars, int nw, int s3) {
+#define CS_PICK_S(G, NW)                                                                           \
+  return s3 ? (const void *)cs_propagate_ne_packed<G, NW, true> : (const void *)cs_propagate_ne_packed<G, NW, false>;
+#define CS_PICK_NW(G)                                                                              \
+  if (nw == 1) { CS_PICK_S(G, 1) }                                                                 \
+  CS_PICK_S(G, 2)
+  if (n_vars <= 16) { CS_PICK_NW(4) }
+  CS_PICK_NW(2)
+#undef CS_PICK_NW
+#undef CS_PICK_S
 }
 
 /* ---- finalize ---------------------------------------------------------------------- */
@@ -608,9 +622,27 @@ extern "C" int csgpu_model_finalize(csgpu_model *m) {
           for (int variant = 0; variant < 4; variant++)
             if ((rc = lds_limit(bytes, ne_regs_kernel(m->img->dense_width, m->fb_words, h->n_vars, variant & 1, variant >> 1))))
               return rc;
-          if (packed_nodes_per_wave(m->fb_words, h->n_vars) &&
-              (rc = lds_limit(bytes, ne_packed_kernel(m->img->dense_width, h->n_vars))))
-            return rc;
+          m->packed_nw = 1; /* one set word per variable when every root domain has at most 32 values */
+          for (int32_t v = 0; v < h->n_vars; v++)
+            if ((int64_t)h->dom[v].hi - (int64_t)h->dom[v].lo + 1 > 32) m->packed_nw = 2;
+          m->packed_bias = 0;
+          for (int32_t v = 0; v < h->n_vars; v++)
+            if (h->dom[v].lo - m->img->dense_dmin > m->packed_bias) m->packed_bias = h->dom[v].lo - m->img->dense_dmin;
+          if (packed_nodes_per_wave(m->fb_words, h->n_vars, m->img->dense_width)) {
+            if ((rc = lds_limit(2 * bytes, ne_packed_kernel(h->n_vars, m->packed_nw, m->img->dense_slots == 3)))) return rc;
+            /* entry e of row u becomes e - (root_lo[u] - dmin) + bias (cs_kernels.hip.h, kernel 5) */
+            const size_t per_row = (size_t)m->img->dense_slots * m->img->dense_cols, total = (size_t)h->n_vars * per_row;
+            uint16_t *rel = (uint16_t *)malloc(total * sizeof(uint16_t));
+            const uint8_t *src = (const uint8_t *)m->img->dense_tab;
+            for (size_t i = 0; i < total; i++) {
+              const int32_t u = (int32_t)(i / per_row);
+              rel[i] = src[i] == 0xffu ? (uint16_t)0xffffu
+                                       : (uint16_t)((int)src[i] - (h->dom[u].lo - m->img->dense_dmin) + m->packed_bias);
+            }
+            rc = upload(rel, total * sizeof(uint16_t), (int **)&m->d_packed_tab);
+            free(rel);
+            if (rc) return rc;
+          }
         }
       }
     }
@@ -645,7 +677,7 @@ extern "C" int csgpu_model_set_kernel(csgpu_model *m, int which) {
     if (which == 3 && !m->fb_words) return set_err(CSGPU_E_LIMIT, "model does not qualify for the forbidden-set kernel");
     if (which == 4 && !m->dense_waves)
       return set_err(CSGPU_E_LIMIT, "model does not qualify for the register-resident forbidden-set kernel");
-    if (which == 5 && !(m->dense_waves && packed_nodes_per_wave(m->fb_words, m->host->n_vars)))
+    if (which == 5 && !(m->dense_waves && packed_nodes_per_wave(m->fb_words, m->host->n_vars, m->img->dense_width)))
       return set_err(CSGPU_E_LIMIT, "model does not qualify for the several-nodes-per-wave kernel (at most 32 variables, 64 values)");
   }
   m->kernel_choice = which;
@@ -659,7 +691,7 @@ extern "C" int csgpu_model_qualifies(const csgpu_model *m, int which) {
   case 2: return m->lds_waves != 0;
   case 3: return m->fb_words != 0;
   case 4: return m->dense_waves != 0;
-  case 5: return m->dense_waves != 0 && packed_nodes_per_wave(m->fb_words, m->host->n_vars) != 0;
+  case 5: return m->dense_waves != 0 && packed_nodes_per_wave(m->fb_words, m->host->n_vars, m->img->dense_width) != 0;
   default: return 0;
   }
 }
@@ -688,14 +720,16 @@ static int launch_regs(const csgpu_model *m, const csgpu_val *d_states_in, const
   long long nb_d = (long long)batch;
   void *args_d[] = { &n, &tab_d, &slots, &dmin_d, &root_lo_d, &sym_off, &d_states_in, &d_forb_in, &d_nodes,
                      &d_states_out, &d_forb_out, &d_results, &nb_d, &d_batch, &csz, &flags };
-  const int per_wave = sets_only || m->kernel_choice == 4 ? 0 : packed_nodes_per_wave(m->fb_words, n);
+  const int per_wave = sets_only || m->kernel_choice == 4 ? 0 : packed_nodes_per_wave(m->fb_words, n, m->img->dense_width);
   if (per_wave) { /* kernel 5: one wave per group of nodes, grid-stride */
     const int64_t groups = (batch + per_wave - 1) / per_wave;
     int64_t gp = (int64_t)m->n_cus * (int64_t)wgs * 2;
     const int64_t need_gp = (groups + m->dense_waves - 1) / m->dense_waves;
     if (gp > need_gp) gp = need_gp;
-    HIP_TRY(hipLaunchKernel(ne_packed_kernel(m->img->dense_width, n), dim3((unsigned)gp),
-                            dim3((unsigned)(m->dense_waves * CS_WAVE)), args_d, m->dense_bytes, (hipStream_t)stream));
+    csz = m->packed_bias; /* this kernel's arguments in those positions */
+    tab_d = m->d_packed_tab;
+    HIP_TRY(hipLaunchKernel(ne_packed_kernel(n, m->packed_nw, slots == 3), dim3((unsigned)gp),
+                            dim3((unsigned)(m->dense_waves * CS_WAVE)), args_d, 2 * m->dense_bytes, (hipStream_t)stream));
     return CSGPU_OK;
   }
   const int chunks_v = (n + CS_WAVE - 1) / CS_WAVE;

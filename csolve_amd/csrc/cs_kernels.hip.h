@@ -1329,10 +1329,20 @@ __global__ __launch_bounds__(1024, (FW * R <= 1 ? 8 : 4)) void cs_propagate_ne_r
  *
  * A model of n <= 64 / G variables with 64-value windows leaves most lanes of kernel 4 idle (queens-16: 16 of
  * 64).  Here a wave carries G = 2 or 4 nodes at once, node g in lanes g S .. g S + S - 1 (S = 64 / G).  Every
- * segment runs its own event queue: the ballot of newly valued variables is cut into G segments, each lane
- * follows the lowest set bit of its own segment, fetches that variable's value with ds_bpermute and reads that
- * variable's table row.  A segment whose node failed stops pushing; the wave leaves the loop when no segment
- * has anything left.  Results per node are those of kernel 4 (status, props, revisions, rounds). */
+ * segment runs its own event queue: the ballot of newly valued variables is cut into G segments on the scalar
+ * unit, each lane follows the lowest set bit of its own segment, fetches that variable's value with
+ * ds_bpermute and reads that variable's table row.  A segment whose node failed stops pushing; the wave leaves
+ * the loop when no segment has anything left.  Results per node are those of kernel 4 (status, props,
+ * revisions, rounds).
+ *
+ * The kernel is VALU-bound (the search engine's children are mostly cut, so little is stored), hence:
+ *  - per-node flags (failed, pushed, rounds, open variables) are wave masks / packed fields in SGPRs, turned
+ *    into lane predicates with the inverse ballot; only bounds and sets are per-lane arithmetic;
+ *  - bounds are kept relative to the variable's root lower bound (= bit positions of its set);
+ *  - NW = 1: every root domain has at most 32 values, one set word per variable (the high word of the stored
+ *    u64 is passed through); S3: exactly three table slots per pair (queens), read with immediate offsets.
+ * Set bits of values outside a variable's root domain are unspecified (kernels 3 and 4 mark pushes that land
+ * there, NW = 1 does not); they never influence a result. */
 template <int S>
 __device__ __forceinline__ int cs_segment_sum(int x) { /* valid in the last lane of every S-lane segment */
   x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true); /* row_shr:1 */
@@ -1343,33 +1353,77 @@ __device__ __forceinline__ int cs_segment_sum(int x) { /* valid in the last lane
   return x;
 }
 
-/* this lane's segment of a wave mask (32-bit operations only) */
+/* wave mask -> bit 0 of every segment that has a bit set (uniform: scalar unit, no loops over segments) */
 template <int G>
-__device__ __forceinline__ unsigned cs_segment_of(unsigned long long mask, int g) {
-  const unsigned lo = (unsigned)mask, hi = (unsigned)(mask >> 32);
+__device__ __forceinline__ unsigned long long cs_segments_low_bit(unsigned long long m) {
+  constexpr int S = CS_WAVE / G;
+  constexpr unsigned long long HI = G == 4 ? 0x8000800080008000ull : 0x8000000080000000ull;
+  return ((((m & ~HI) + ~HI) | m) & HI) >> (S - 1);
+}
+
+/* ... -> every segment that has a bit set, filled */
+template <int G>
+__device__ __forceinline__ unsigned long long cs_segments_any(unsigned long long m) {
+  constexpr int S = CS_WAVE / G;
+  const unsigned long long low = cs_segments_low_bit<G>(m), hi = low << (S - 1);
+  return (hi - low) | hi;
+}
+
+/* this lane's S-bit field of a uniform 64-bit word (32-bit operations only) */
+template <int G>
+__device__ __forceinline__ unsigned cs_segment_field(unsigned long long x, int g) {
+  const unsigned lo = (unsigned)x, hi = (unsigned)(x >> 32);
   if (G == 2) return g ? hi : lo;
   const unsigned h = (g & 2) ? hi : lo;
   return (g & 1) ? h >> 16 : h & 0xffffu;
 }
 
-template <typename E, int G>
+/* minimum over the S lanes of a segment, in every lane of it: DPP row rotations (a row = 16 lanes), plus one
+ * swizzle that swaps the two rows of a 32-lane segment */
+template <int S>
+__device__ __forceinline__ unsigned cs_segment_min(unsigned x) {
+  /* v_min_u32 with the rotated operand read through DPP (the compiler emits mov_dpp + min + copy for the
+   * same thing); a DPP read needs two wait states after the VALU write of its source */
+  asm("s_nop 1\n\t"
+      "v_min_u32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_min_u32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_min_u32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_min_u32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf"
+      : "+v"(x));
+  if (S == 32) {
+    const unsigned y = (unsigned)__builtin_amdgcn_ds_swizzle((int)x, 0x401f); /* lane ^ 16 */
+    x = y < x ? y : x;
+  }
+  return x;
+}
+
+/* This kernel's table (built at finalize from the dense table) has 16-bit entries relative to the PUSHING
+ * variable's root lower bound: with u at relative value r, bit r + bias - t[u][slot][w] of w's set is forbidden
+ * (bias = the largest root_lo - dmin keeps every entry non-negative; 0xffff = no clause).  The pushed variable and its value then
+ * travel together in one key (variable in the top bits, r + bias below), and the segment minimum of the keys of
+ * the pending lanes IS the next event: no ds_bpermute, no scalar bookkeeping per event. */
+template <int G, int NW, bool S3>
 __global__ __launch_bounds__(1024, 8) void cs_propagate_ne_packed(
-    int n, const E *__restrict__ tab_g, int slots, int dmin, const int *__restrict__ root_lo,
-    const int *__restrict__ sym_off, const cs_val *__restrict__ states_in,
+    int n, const unsigned short *__restrict__ tab_g /* the relative table */, int slots, int dmin /* unused */,
+    const int *__restrict__ root_lo, const int *__restrict__ sym_off, const cs_val *__restrict__ states_in,
     const unsigned long long *__restrict__ forb_in, const cs_node_in *__restrict__ nodes,
     cs_val *__restrict__ states_out, unsigned long long *__restrict__ forb_out, cs_node_out *__restrict__ results,
-    long long batch, const unsigned long long *__restrict__ batch_dev, int csz /* unused */, int flags) {
+    long long batch, const unsigned long long *__restrict__ batch_dev, int bias, int flags) {
   extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
   constexpr int S = CS_WAVE / G;
   constexpr int W = CS_WAVE; /* columns of the table */
-  constexpr unsigned long long SEG = (1ull << S) - 1ull;
+  constexpr int TOP = 32 * NW - 1; /* highest relative value */
+  constexpr unsigned KEY_VALUE = (1u << 26) - 1u; /* key = variable << 26 | relative value + bias */
   if (batch_dev != nullptr && (long long)*batch_dev < batch) batch = (long long)*batch_dev;
   const int lane = threadIdx.x & (CS_WAVE - 1);
   const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int waves_per_block = blockDim.x >> 6;
-  E *s_tab = (E *)cs_lds;
+  unsigned short *s_tab = (unsigned short *)cs_lds;
   {
-    const int vecs = (int)(((size_t)n * slots * W * sizeof(E)) / 16);
+    const int vecs = (int)(((size_t)n * slots * W * 2) / 16);
     const uint4 *src = (const uint4 *)tab_g;
     uint4 *dst = (uint4 *)cs_lds;
     for (int i = threadIdx.x; i < vecs; i += blockDim.x) dst[i] = src[i];
@@ -1381,6 +1435,8 @@ __global__ __launch_bounds__(1024, 8) void cs_propagate_ne_packed(
   const int vcl = live ? v : n - 1;
   const int b0 = live ? root_lo[vcl] : 0;
   const int deg = live ? sym_off[vcl + 1] - sym_off[vcl] : 0;
+  const unsigned key_base = ((unsigned)v << 26) + (unsigned)bias;
+  const int row_stride = slots * W * 2;
   const bool have_in = forb_in != nullptr;
   const uint2 *forb_in2 = (const uint2 *)forb_in;
   uint2 *forb_out2 = (uint2 *)forb_out;
@@ -1405,8 +1461,12 @@ __global__ __launch_bounds__(1024, 8) void cs_propagate_ne_packed(
     const long long node = q * G + g;
     const bool valid = node < batch;
     const int nvar = rec_n.var, nlo = rec_n.lo, nhi = rec_n.hi;
-    int lo = live ? pd_n.lo : 0, hi = live ? pd_n.hi : 0;
-    unsigned fb[2]; /* a lane without a variable behaves like a variable fixed at its window's first value */
+    /* bounds relative to the root lower bound = bit positions; a lane without a variable behaves like a
+     * variable fixed at its window's first value */
+    int rl = live ? pd_n.lo - b0 : 0, rh = live ? pd_n.hi - b0 : 0;
+    rl = rl < 0 ? 0 : (rl > TOP ? TOP : rl); /* states outside the root domain are not valid input: stay defined */
+    rh = rh < 0 ? 0 : (rh > TOP ? TOP : rh);
+    unsigned fb[2];
     fb[0] = live ? pf_n.x : 0xfffffffeu;
     fb[1] = live ? pf_n.y : 0xffffffffu;
     {
@@ -1420,67 +1480,78 @@ __global__ __launch_bounds__(1024, 8) void cs_propagate_ne_packed(
 
     /* the assignment (step_enter, csolve.c:294-304) and the first variables to push */
     const bool mine = nvar >= 0 && v == nvar;
-    if ((flags & CS_K4_OUT_RESTRICT) && mine) cs_set_restrict<2>(fb, nlo - b0, nhi - b0);
-    if (mine) { lo = nlo; hi = nhi; }
-    bool pushme = live && lo == hi && (!have_in || nvar < 0 || mine);
-    const int lo0 = lo, hi0 = hi;
-    int rounds = 0, myrev = 0;
-    bool failed = false;
+    const int lo_in = b0 + rl, hi_in = b0 + rh;
+    if (mine) {
+      const long long from = (long long)nlo - b0, to = (long long)nhi - b0;
+      if (from > TOP || to < 0 || from > to) { /* nothing of the root domain left */
+        fb[0] = 0xffffffffu;
+        fb[1] = 0xffffffffu;
+      } else {
+        if (flags & CS_K4_OUT_RESTRICT) cs_set_restrict<2>(fb, (int)from, (int)to);
+        rl = from < 0 ? 0 : (int)from;
+        rh = to > TOP ? TOP : (int)to;
+      }
+    }
+    /* kernel 4's reference point for the count of propagations: the assigned interval itself */
+    const int lo0 = mine ? nlo : lo_in, hi0 = mine ? nhi : hi_in;
+    bool pending = live && rl == rh && (!have_in || nvar < 0 || mine);
+    unsigned long long failedm = 0ull, pushedm = __ballot(pending);
+    unsigned long long rounds_fields = 0ull; /* one S-bit counter per segment */
     for (;;) {
       /* (1) newly valued variables push their forbidden value into the sets of their own node */
-      unsigned long long pm = __ballot(pushme);
-      myrev += pushme ? deg : 0;
-      while (pm != 0ull) {
-        const unsigned seg = cs_segment_of<G>(pm, g);
-        const bool act = seg != 0u;
-        const int ul = act ? __builtin_ctz(seg) : 0;
-        {
-          unsigned long long rest = 0ull; /* every segment drops its lowest bit (scalar) */
-#pragma unroll
-          for (int gg = 0; gg < G; gg++) {
-            unsigned long long sg = (pm >> (gg * S)) & SEG;
-            sg &= sg - 1ull;
-            rest |= sg << (gg * S);
-          }
-          pm = rest;
-        }
-        int cd = __builtin_amdgcn_ds_bpermute(((lane & ~(S - 1)) + ul) << 2, lo) - dmin;
-        cd = act ? cd : 0x40000000; /* selects no word below */
-        const E *row = s_tab + (size_t)ul * slots * W + v;
-        for (int k0 = 0; k0 < slots; k0 += 3) {
-          const int k1 = k0 + 1 < slots ? k0 + 1 : slots - 1, k2 = k0 + 2 < slots ? k0 + 2 : slots - 1;
-          E e[3];
-          e[0] = row[k0 * W];
-          e[1] = row[k1 * W];
-          e[2] = row[k2 * W];
-#pragma unroll
-          for (int t = 0; t < 3; t++) {
-            const unsigned bit = (unsigned)(cd - (int)e[t]);
-            const unsigned sel = bit >> 5, m = 1u << (bit & 31u);
-            fb[0] |= sel == 0u ? m : 0u;
-            fb[1] |= sel == 1u ? m : 0u;
+      while (__ballot(pending) != 0ull) {
+        const unsigned key = cs_segment_min<S>(pending ? key_base + (unsigned)rl : 0xffffffffu);
+        const int ul = (int)(key >> 26);           /* 63: nothing pending in this segment */
+        const int cd = (int)(key & KEY_VALUE);     /* then 2^26 - 1: selects no bit below */
+        pending = pending && v != ul;
+        const int ulc = ul < n ? ul : n - 1;
+        const unsigned char *row = (const unsigned char *)s_tab + ulc * row_stride + v * 2;
+        if (S3) {
+          const int e0 = (int)*(const unsigned short *)(row), e1 = (int)*(const unsigned short *)(row + W * 2),
+                    e2 = (int)*(const unsigned short *)(row + 2 * W * 2);
+          const unsigned b0_ = (unsigned)(cd - e0), b1_ = (unsigned)(cd - e1), b2_ = (unsigned)(cd - e2);
+          fb[0] |= (b0_ < 32u ? 1u << b0_ : 0u) | (b1_ < 32u ? 1u << b1_ : 0u) | (b2_ < 32u ? 1u << b2_ : 0u);
+          if (NW == 2)
+            fb[1] |= ((b0_ >> 5) == 1u ? 1u << (b0_ & 31u) : 0u) | ((b1_ >> 5) == 1u ? 1u << (b1_ & 31u) : 0u) |
+                     ((b2_ >> 5) == 1u ? 1u << (b2_ & 31u) : 0u);
+        } else {
+          for (int k = 0; k < slots; k++) {
+            const unsigned bit = (unsigned)(cd - (int)*(const unsigned short *)(row + (size_t)k * W * 2));
+            fb[0] |= bit < 32u ? 1u << bit : 0u;
+            if (NW == 2) fb[1] |= (bit >> 5) == 1u ? 1u << (bit & 31u) : 0u;
           }
         }
       }
-      /* (2) bounds from the sets */
+      /* (2) bounds from the sets: lowest and highest allowed position within [rl, rh] */
       int first, last;
-      cs_set_bounds<2>(fb, lo - b0, hi - b0, &first, &last);
-      const bool bad = last < 0;
-      const int nlo2 = b0 + first, nhi2 = b0 + last;
-      const bool newly = !bad && (nlo2 != lo || nhi2 != hi) && nlo2 == nhi2;
-      lo = bad ? lo : nlo2;
-      hi = bad ? hi : nhi2;
-      failed = failed || cs_segment_of<G>(__ballot(bad), g) != 0u;
-      pushme = newly && !failed;
-      const unsigned long long am = __ballot(pushme);
-      if (am == 0ull) break;
-      rounds += cs_segment_of<G>(am, g) != 0u ? 1 : 0;
+      bool bad;
+      if (NW == 1) {
+        const unsigned a = ~fb[0] & (~0u << rl) & (~0u >> (31 - rh));
+        bad = a == 0u;
+        first = __builtin_ctz(a | 0x80000000u); /* defined for a == 0 as well */
+        last = 31 - __builtin_clz(a | 1u);
+      } else {
+        cs_set_bounds<2>(fb, rl, rh, &first, &last);
+        bad = last < 0;
+      }
+      const bool newly = !bad && first == last && rl != rh;
+      rl = bad ? rl : first;
+      rh = bad ? rh : last;
+      const unsigned long long badm = __ballot(bad);
+      if (badm != 0ull) failedm |= cs_segments_any<G>(badm);
+      const unsigned long long newm = __ballot(newly) & ~failedm;
+      if (newm == 0ull) break;
+      pending = __builtin_amdgcn_inverse_ballot_w64(newm);
+      pushedm |= newm;
+      rounds_fields += cs_segments_low_bit<G>(newm);
     }
 
-    const int open_vars = __popc(cs_segment_of<G>(__ballot(lo != hi), g));
+    const int open_vars = __popc(cs_segment_field<G>(__ballot(rl != rh), g));
+    const int lo = b0 + rl, hi = b0 + rh;
     const int props = cs_segment_sum<S>((lo - lo0) + (hi0 - hi));
-    const int revisions = cs_segment_sum<S>(myrev);
-    if (flags & CS_K4_OUT_RESTRICT) cs_set_restrict<2>(fb, lo - b0, hi - b0);
+    const int revisions = cs_segment_sum<S>(__builtin_amdgcn_inverse_ballot_w64(pushedm) ? deg : 0);
+    const bool failed = __builtin_amdgcn_inverse_ballot_w64(failedm);
+    if (flags & CS_K4_OUT_RESTRICT) cs_set_restrict<2>(fb, rl, rh);
     const bool st = valid && live && !failed;
     const size_t orow = (size_t)node * n + v;
     if (st && states_out != nullptr) states_out[orow] = cs_interval(lo, hi);
@@ -1490,7 +1561,7 @@ __global__ __launch_bounds__(1024, 8) void cs_propagate_ne_packed(
       r.status = failed ? -1 : open_vars;
       r.props = props;
       r.revisions = revisions;
-      r.rounds = rounds;
+      r.rounds = (int)cs_segment_field<G>(rounds_fields, g);
       results[node] = r;
     }
   }

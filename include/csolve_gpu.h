@@ -178,7 +178,9 @@ int csgpu_propagate_batch_obj(const csgpu_model *m, const csgpu_val *d_states_in
  *   d_forb_out [batch][n_vars][FW] uint64, rows parallel to d_states_out (NULL: not wanted)
  * Results (fixpoints, verdicts, PROPS of consistent nodes) are those of csgpu_propagate_batch.
  * Rows of inconsistent nodes (status -1) in d_states_out / d_forb_out are unspecified: the register-resident
- * kernel stores them unconditionally, the other kernels leave them untouched. */
+ * kernel stores them unconditionally, the other kernels leave them untouched.  Bits of values outside a
+ * variable's root domain are unspecified as well (a push may or may not be recorded there); they never
+ * influence a result, and sets written by one kernel may be fed to another. */
 int csgpu_model_forbidden_words(const csgpu_model *m); /* 0: the model does not qualify */
 int csgpu_propagate_batch_fb(const csgpu_model *m, const csgpu_val *d_states_in, const uint64_t *d_forb_in,
                              const csgpu_node *d_nodes, csgpu_val *d_states_out, uint64_t *d_forb_out,

@@ -328,8 +328,21 @@ def test_large_batches_agree_across_kernels(kind, size, count):
             if k in sets:
                 assert torch.equal(f[ok], sets[k]), (k, launch)
             sets[k] = f[ok]
+    # the sets agree on every value of the variables' root domains (bits of values outside a root domain are
+    # unspecified: kernel 5 leaves the high word alone when all root domains fit 32 values)
+    dom = model.domains()
+    fw = model.forbidden_words()
+    width = (dom[:, 1].astype(np.int64) - dom[:, 0] + 1)
+    mask = np.zeros((model.n_vars, fw), dtype=np.uint64)
+    for v in range(model.n_vars):
+        for q in range(fw):
+            bits = int(min(max(width[v] - 64 * q, 0), 64))
+            mask[v, q] = np.uint64((1 << bits) - 1) if bits < 64 else np.uint64(0xFFFFFFFFFFFFFFFF)
+    d_mask = torch.from_numpy(mask.view(np.int64)).cuda()
     for k in sets:
-        assert torch.equal(sets[3], sets[k]), k
+        assert torch.equal(sets[3] & d_mask, sets[k] & d_mask), k
+        if k != 5:
+            assert torch.equal(sets[3], sets[k]), k
 
 
 @pytest.mark.parametrize("name", ["ref_schedule", "schedule6_s1", "ref_wcet"])

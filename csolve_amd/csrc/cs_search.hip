@@ -38,7 +38,7 @@ struct csgpu_search {
   csgpu_node *d_nodes;
   cs_val *d_child_states, *d_complete_states;
   csgpu_result *d_results;
-  int *d_dest, *d_complete_list, *d_truth;
+  int *d_dest /* survivor k = child d_dest[k] */, *d_complete_list, *d_truth;
   int *d_block_surv, *d_block_comp, *d_block_cuts, *d_block_props, *d_block_revs, *d_surv_off, *d_comp_off;
   unsigned long long *d_counters; /* [C_COUNT] */
   int *d_best;                    /* = (int *)&d_counters[C_BEST] */
@@ -362,8 +362,8 @@ __global__ __launch_bounds__(SB) void cs_classify_count(const csgpu_result *__re
 }
 
 __global__ __launch_bounds__(SB) void cs_classify_assign(const csgpu_result *__restrict__ res, int children,
-                                                         long long new_top, const int *__restrict__ surv_off,
-                                                         const int *__restrict__ comp_off, int *__restrict__ dest,
+                                                         const int *__restrict__ surv_off,
+                                                         const int *__restrict__ comp_off, int *__restrict__ surv_list,
                                                          int *__restrict__ complete_list) {
   __shared__ int s_surv[SB], s_comp[SB];
   const int t = threadIdx.x, i = blockIdx.x * SB + t;
@@ -380,15 +380,15 @@ __global__ __launch_bounds__(SB) void cs_classify_assign(const csgpu_result *__r
     __syncthreads();
   }
   if (i < children) {
-    dest[i] = surv ? (int)(new_top + surv_off[blockIdx.x] + s_surv[t] - 1) : -1;
+    if (surv) surv_list[surv_off[blockIdx.x] + s_surv[t] - 1] = i; /* survivor k goes to pool row new_top + k */
     if (comp) complete_list[comp_off[blockIdx.x] + s_comp[t] - 1] = i;
   }
 }
 
 /* small iterations: cs_classify_count + cs_scan_classes + cs_classify_assign in one workgroup, the number of
  * children read from the device.  Same rows and the same order as the large path (tiles in child order). */
-__global__ __launch_bounds__(1024) void cs_classify_small(const csgpu_result *__restrict__ res, long long new_top,
-                                                          int *__restrict__ dest, int *__restrict__ complete_list,
+__global__ __launch_bounds__(1024) void cs_classify_small(const csgpu_result *__restrict__ res,
+                                                          int *__restrict__ surv_list, int *__restrict__ complete_list,
                                                           unsigned long long *__restrict__ counters) {
   __shared__ long long s_part[16];
   const int children = (int)counters[C_TOTAL_CHILDREN];
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(1024) void cs_classify_small(const csgpu_result *__
     const long long x = (long long)(status > 0) | ((long long)(status == 0) << 32);
     const long long ex = carry + cs_block_excl_scan(x, s_part, &total);
     if (i < children) {
-      dest[i] = status > 0 ? (int)(new_top + (ex & 0xffffffffll)) : -1;
+      if (status > 0) surv_list[ex & 0xffffffffll] = i;
       if (status == 0) complete_list[ex >> 32] = i;
     }
     carry += total;
@@ -425,34 +425,33 @@ __global__ __launch_bounds__(1024) void cs_classify_small(const csgpu_result *__
   }
 }
 
-/* copy survivors into their pool rows: a workgroup takes cpb (at most SB) consecutive children and walks their
- * cpb * n elements flat, so that small models fill the lanes too (dest < 0: not a survivor) */
-__global__ __launch_bounds__(SB) void cs_scatter(const cs_val *__restrict__ child_states, const int *__restrict__ dest,
-                                                 int children, int n, cs_val *__restrict__ pool,
+/* copy survivor k (child surv_list[k]) into pool row new_top + k: a workgroup takes cpb (at most SB) consecutive
+ * survivors and walks their cpb * n elements flat, so that small models fill the lanes too.  The number of
+ * survivors is on the device; the grid is sized for the number of children. */
+__global__ __launch_bounds__(SB) void cs_scatter(const cs_val *__restrict__ child_states, const int *__restrict__ surv_list,
+                                                 const unsigned long long *__restrict__ counters, long long new_top, int n,
+                                                 cs_val *__restrict__ pool,
                                                  const unsigned long long *__restrict__ child_forb,
-                                                 unsigned long long *__restrict__ pool_forb, int fw,
-                                                 const unsigned long long *__restrict__ children_dev, int cpb) {
-  __shared__ int s_dest[SB];
-  if (children_dev != nullptr && (unsigned long long)children > *children_dev) children = (int)*children_dev;
+                                                 unsigned long long *__restrict__ pool_forb, int fw, int cpb) {
+  __shared__ int s_src[SB];
+  const long long survivors = (long long)counters[C_SURVIVORS];
   const long long base = (long long)blockIdx.x * cpb;
-  if (base >= children) return;
-  const int here = children - base < cpb ? (int)(children - base) : cpb;
-  if ((int)threadIdx.x < here) s_dest[threadIdx.x] = dest[base + threadIdx.x];
+  if (base >= survivors) return;
+  const int here = survivors - base < cpb ? (int)(survivors - base) : cpb;
+  if ((int)threadIdx.x < here) s_src[threadIdx.x] = surv_list[base + threadIdx.x];
   __syncthreads();
   const unsigned total = (unsigned)here * (unsigned)n;
-  const cs_val *src = child_states + (size_t)base * n;
+  cs_val *dst = pool + (size_t)(new_top + base) * n;
   for (unsigned e = threadIdx.x; e < total; e += SB) {
     const unsigned c = e / (unsigned)n, v = e - c * (unsigned)n;
-    const int d = s_dest[c];
-    if (d >= 0) pool[(size_t)d * n + v] = src[e];
+    dst[e] = child_states[(size_t)s_src[c] * n + v];
   }
   if (fw > 0) {
-    const unsigned long long *fs = child_forb + (size_t)base * n * fw;
     const unsigned nf = (unsigned)n * (unsigned)fw, total_f = (unsigned)here * nf;
+    unsigned long long *fd = pool_forb + (size_t)(new_top + base) * nf;
     for (unsigned e = threadIdx.x; e < total_f; e += SB) {
       const unsigned c = e / nf, k = e - c * nf;
-      const int d = s_dest[c];
-      if (d >= 0) pool_forb[(size_t)d * nf + k] = fs[e];
+      fd[e] = child_forb[(size_t)s_src[c] * nf + k];
     }
   }
 }
@@ -907,15 +906,15 @@ static int one_iteration(csgpu_search *s) {
   if (rc != CSGPU_OK) return rc;
   const unsigned cb = (unsigned)((children + SB - 1) / SB);
   if (small) {
-    hipLaunchKernelGGL(cs_classify_small, dim3(1), dim3(1024), 0, 0, s->d_results, (long long)s->top, s->d_dest,
-                       s->d_complete_list, s->d_counters);
+    hipLaunchKernelGGL(cs_classify_small, dim3(1), dim3(1024), 0, 0, s->d_results, s->d_dest, s->d_complete_list,
+                       s->d_counters);
   } else {
     hipLaunchKernelGGL(cs_classify_count, dim3(cb), dim3(SB), 0, 0, s->d_results, (int)children, s->d_block_surv,
                        s->d_block_comp, s->d_block_cuts, s->d_block_props, s->d_block_revs);
     hipLaunchKernelGGL(cs_scan_classes, dim3(1), dim3(1024), 0, 0, s->d_block_surv, s->d_block_comp, s->d_block_cuts,
                        s->d_block_props, s->d_block_revs, (int)cb, s->d_surv_off, s->d_comp_off, s->d_counters);
-    hipLaunchKernelGGL(cs_classify_assign, dim3(cb), dim3(SB), 0, 0, s->d_results, (int)children, (long long)s->top,
-                       s->d_surv_off, s->d_comp_off, s->d_dest, s->d_complete_list);
+    hipLaunchKernelGGL(cs_classify_assign, dim3(cb), dim3(SB), 0, 0, s->d_results, (int)children, s->d_surv_off,
+                       s->d_comp_off, s->d_dest, s->d_complete_list);
   }
   {
     /* about 4096 state elements per workgroup, fewer when that would leave most of the machine idle */
@@ -923,8 +922,7 @@ static int one_iteration(csgpu_search *s) {
     cpb = cpb < 4 ? 4 : (cpb > SB ? SB : cpb);
     while (cpb > 4 && children / cpb < 2048) cpb >>= 1;
     hipLaunchKernelGGL(cs_scatter, dim3((unsigned)((children + cpb - 1) / cpb)), dim3(SB), 0, 0, s->d_child_states, s->d_dest,
-                       (int)children, n, s->pool, s->d_child_forb, s->pool_forb, s->fw,
-                       (const unsigned long long *)d_children, cpb);
+                       s->d_counters, (long long)s->top, n, s->pool, s->d_child_forb, s->pool_forb, s->fw, cpb);
   }
   /* the (only, for a small iteration) host read: class counts, the real number of children, and what the
    * previous iteration's accept left behind */

@@ -263,6 +263,8 @@ static int upload_image(const cs_dev_image *g, dev_tables_owner *o, cs_tables *t
   t->obj_var = -1;
   t->obj_lo = CS_DOM_MIN;
   t->obj_hi = CS_DOM_MAX;
+  t->obj_best_dev = NULL;
+  t->obj_sense = 0;
   return CSGPU_OK;
 }
 
@@ -885,6 +887,16 @@ extern "C" int csgpu_propagate_batch_obj(const csgpu_model *m, const csgpu_val *
 extern "C" int csgpu_internal_propagate_obj(const csgpu_model *m, const csgpu_val *d_states_in, const csgpu_node *d_nodes,
                                             csgpu_val *d_states_out, csgpu_result *d_results, int64_t batch,
                                             const uint64_t *d_batch, int32_t obj_lo, int32_t obj_hi, void *stream) {
+  return csgpu_internal_propagate_objdev(m, d_states_in, d_nodes, d_states_out, d_results, batch, d_batch, obj_lo, obj_hi,
+                                         NULL, 0, stream);
+}
+
+/* d_best (nullable) / sense: the incumbent is read from device memory when the kernel starts */
+extern "C" int csgpu_internal_propagate_objdev(const csgpu_model *m, const csgpu_val *d_states_in,
+                                               const csgpu_node *d_nodes, csgpu_val *d_states_out,
+                                               csgpu_result *d_results, int64_t batch, const uint64_t *d_batch,
+                                               int32_t obj_lo, int32_t obj_hi, const int32_t *d_best, int sense,
+                                               void *stream) {
   if (m == NULL || batch < 0) return set_err(CSGPU_E_ARG, "null argument");
   if (!m->finalized) return set_err(CSGPU_E_STATE, "model is not finalized");
   if (batch == 0) return CSGPU_OK; /* an empty batch needs no buffers */
@@ -905,10 +917,14 @@ extern "C" int csgpu_internal_propagate_obj(const csgpu_model *m, const csgpu_va
   cs_val *out = (cs_val *)d_states_out;
   cs_node_out *res = (cs_node_out *)d_results;
   cs_tables tab = m->tab;
-  if (m->host->obj_var >= 0 && (obj_lo != CS_DOM_MIN || obj_hi != CS_DOM_MAX)) {
+  if (m->host->obj_var >= 0 && (obj_lo != CS_DOM_MIN || obj_hi != CS_DOM_MAX || (d_best != NULL && sense != 0))) {
     tab.obj_var = m->host->obj_var;
     tab.obj_lo = obj_lo;
     tab.obj_hi = obj_hi;
+    if (d_best != NULL && sense != 0) {
+      tab.obj_best_dev = d_best;
+      tab.obj_sense = sense;
+    }
   }
   if (m->kernel_choice >= 3 && tab.obj_var < 0)
     return csgpu_internal_propagate_fb(m, d_states_in, NULL, d_nodes, d_states_out, NULL, d_results, batch, d_batch, stream);
@@ -955,7 +971,22 @@ extern "C" int csgpu_eval_batch(const csgpu_model *m, const csgpu_val *d_states,
   if (batch > 0x7fffffff) return set_err(CSGPU_E_LIMIT, "batch too large");
   const size_t lds = (size_t)m->host->n_vars * sizeof(cs_val) + 16;
   hipLaunchKernelGGL(cs_eval_root, dim3((unsigned)batch), dim3(CS_BLOCK), lds, (hipStream_t)stream, m->tab,
-                     (const cs_val *)d_states, d_truth);
+                     (const cs_val *)d_states, d_truth, (const int *)NULL, (const unsigned long long *)NULL);
+  HIP_TRY(hipGetLastError());
+  return CSGPU_OK;
+}
+
+/* instance i = row d_list[i] of d_states, i < *d_count <= bound (the count stays on the device) */
+extern "C" int csgpu_internal_eval_list(const csgpu_model *m, const csgpu_val *d_states, const int32_t *d_list,
+                                        const uint64_t *d_count, int64_t bound, int32_t *d_truth, void *stream) {
+  if (m == NULL || d_states == NULL || d_list == NULL || d_count == NULL || d_truth == NULL || bound < 0)
+    return set_err(CSGPU_E_ARG, "null argument");
+  if (!m->finalized) return set_err(CSGPU_E_STATE, "model is not finalized");
+  if (bound == 0) return CSGPU_OK;
+  if (bound > 0x7fffffff) return set_err(CSGPU_E_LIMIT, "batch too large");
+  const size_t lds = (size_t)m->host->n_vars * sizeof(cs_val) + 16;
+  hipLaunchKernelGGL(cs_eval_root, dim3((unsigned)bound), dim3(CS_BLOCK), lds, (hipStream_t)stream, m->tab,
+                     (const cs_val *)d_states, d_truth, (const int *)d_list, (const unsigned long long *)d_count);
   HIP_TRY(hipGetLastError());
   return CSGPU_OK;
 }

@@ -24,6 +24,15 @@ int csgpu_internal_propagate_obj(const csgpu_model *m, const csgpu_val *d_states
                                  csgpu_val *d_states_out, csgpu_result *d_results, int64_t batch,
                                  const uint64_t *d_batch, int32_t obj_lo, int32_t obj_hi, void *stream);
 
+/* ... with the incumbent bound read from device memory (d_best, nullable; sense 1 = minimise, 2 = maximise) */
+int csgpu_internal_propagate_objdev(const csgpu_model *m, const csgpu_val *d_states_in, const csgpu_node *d_nodes,
+                                    csgpu_val *d_states_out, csgpu_result *d_results, int64_t batch,
+                                    const uint64_t *d_batch, int32_t obj_lo, int32_t obj_hi, const int32_t *d_best,
+                                    int sense, void *stream);
+/* csgpu_eval_batch over the rows d_list[0 .. *d_count) of d_states, *d_count <= bound */
+int csgpu_internal_eval_list(const csgpu_model *m, const csgpu_val *d_states, const int32_t *d_list,
+                             const uint64_t *d_count, int64_t bound, int32_t *d_truth, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

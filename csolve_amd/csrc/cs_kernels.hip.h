@@ -66,6 +66,10 @@ struct cs_tables {
   /* objective bound applied to every node before it is propagated (objective_update_val,
    * reference src/objective.c:101-126): dom[obj_var] is intersected with [obj_lo, obj_hi] */
   int obj_var, obj_lo, obj_hi;
+  /* the same bound taken from the incumbent in device memory when the kernel starts (the search engine's
+   * device-driven iterations): sense 1 = minimise (hi = best - 1), 2 = maximise (lo = best + 1) */
+  const int *obj_best_dev;
+  int obj_sense;
 };
 
 struct cs_node_in {
@@ -441,7 +445,13 @@ __global__ __launch_bounds__(CS_BLOCK) void cs_propagate_events(cs_tables T, con
       /* untrailed tightening of "<obj>" by the incumbent; the variable counts as changed only
        * if the bound actually moved (csolve.c:251-252 then re-propagates its clauses) */
       cs_val d = dom[T.obj_var];
-      const int nl = cs_max(d.lo, T.obj_lo), nh = cs_min(d.hi, T.obj_hi);
+      int obj_lo = T.obj_lo, obj_hi = T.obj_hi;
+      if (T.obj_best_dev != nullptr) {
+        const int best = *T.obj_best_dev;
+        if (T.obj_sense == 1) obj_hi = cs_add(best, cs_neg(1));
+        else obj_lo = cs_add(best, 1);
+      }
+      const int nl = cs_max(d.lo, obj_lo), nh = cs_min(d.hi, obj_hi);
       if (nl != d.lo || nh != d.hi) {
         dom[T.obj_var] = cs_interval(nl, nh);
         atomicOr(&mask_a[T.obj_var >> 5], 1u << (T.obj_var & 31));
@@ -1634,14 +1644,18 @@ __global__ __launch_bounds__(CS_BLOCK) void cs_propagate_sweeps(cs_tables T, con
 
 /* ---- three-valued evaluation of the root wide-and (eval.c:233-255) ---------------- */
 
+/* list (nullable): instance i is row list[i] of states; count_dev (nullable): the number of instances, on the
+ * device (the grid is then sized for an upper bound) */
 __global__ __launch_bounds__(CS_BLOCK) void cs_eval_root(cs_tables T, const cs_val *__restrict__ states,
-                                                         int *__restrict__ truth) {
+                                                         int *__restrict__ truth, const int *__restrict__ list,
+                                                         const unsigned long long *__restrict__ count_dev) {
   extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
   const int n = T.n_vars;
   cs_val *dom = (cs_val *)cs_lds;
   unsigned *flags = (unsigned *)(dom + n); /* [0] some clause false, [1] some clause undecided */
   const int inst = blockIdx.x;
-  const cs_val *src = states + (size_t)inst * n;
+  if (count_dev != nullptr && (unsigned long long)inst >= *count_dev) return;
+  const cs_val *src = states + (size_t)(list != nullptr ? list[inst] : inst) * n;
   for (int v = threadIdx.x; v < n; v += blockDim.x) dom[v] = src[v];
   if (threadIdx.x < 2) flags[threadIdx.x] = 0u;
   __syncthreads();

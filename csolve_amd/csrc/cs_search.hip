@@ -23,10 +23,16 @@
 enum { C_SURVIVORS = 0, C_COMPLETE, C_CUTS, C_PROPS, C_REVS, C_TOTAL_CHILDREN, C_PER_ITERATION,
        C_SOLUTIONS = C_PER_ITERATION, C_STORED, C_BEST, C_COUNT };
 
+/* state of the device-driven iterations, in device memory between the kernels of a burst */
+enum { B_TOP = 0, B_BUDGET, B_LIMIT, B_LIMIT_MAX, B_ITER_BASE, B_ITERS, B_NODES, B_CUTS, B_PROPS, B_REVS, B_PEAK, B_ERROR,
+       B_SCATTER_BASE, B_IMPROVED, B_COUNT };
+#define BURST_ITERATIONS 16
+
 struct csgpu_search {
   const csgpu_model *m;
   int n, objective, obj_var;
   int64_t cap, max_children, max_parents, max_width, parents_limit;
+  int64_t parents_max; /* device-driven iterations take up to this many parents when the pool has a backlog */
   double avg_children; /* children per parent of the recent iterations (ALL sizes its batches by it) */
   cs_val *pool;
   int64_t top, peak;
@@ -52,6 +58,12 @@ struct csgpu_search {
   cs_val *seed;
   int64_t seed_count, seed_cap, restart_base, since_restart;
   uint64_t luby_threshold, luby_counter;
+  /* device-driven iterations (ANY / MIN / MAX): BURST_ITERATIONS iterations per host round trip, as one hipGraph */
+  unsigned long long *d_burst, *h_burst; /* [B_COUNT] device / pinned host; h_burst[B_COUNT ...] = copy of the counters */
+  hipStream_t burst_stream;
+  hipGraphExec_t burst_exec;
+  int64_t burst_limit; /* parents per iteration the graph was built for (0: none) */
+  int burst_off;       /* CSGPU_SEARCH_BURST=0 */
 };
 
 extern "C" int csgpu_internal_set_error(int code, const char *msg); /* cs_capi.hip */
@@ -389,7 +401,8 @@ __global__ __launch_bounds__(SB) void cs_classify_assign(const csgpu_result *__r
  * children read from the device.  Same rows and the same order as the large path (tiles in child order). */
 __global__ __launch_bounds__(1024) void cs_classify_small(const csgpu_result *__restrict__ res,
                                                           int *__restrict__ surv_list, int *__restrict__ complete_list,
-                                                          unsigned long long *__restrict__ counters) {
+                                                          unsigned long long *__restrict__ counters,
+                                                          unsigned long long *__restrict__ burst) {
   __shared__ long long s_part[16];
   const int children = (int)counters[C_TOTAL_CHILDREN];
   long long carry = 0; /* survivors in the low half, complete children in the high half: one scan for both */
@@ -422,7 +435,162 @@ __global__ __launch_bounds__(1024) void cs_classify_small(const csgpu_result *__
     counters[C_CUTS] = (unsigned long long)t_cuts;
     counters[C_PROPS] = (unsigned long long)t_props;
     counters[C_REVS] = (unsigned long long)t_revs;
+    if (burst != nullptr) { /* device-driven iterations: the pool top and the running totals live on the device */
+      const unsigned long long base = burst[B_TOP], top = base + (unsigned long long)(carry & 0xffffffffll);
+      burst[B_SCATTER_BASE] = base;
+      burst[B_TOP] = top;
+      if (top > burst[B_PEAK]) burst[B_PEAK] = top;
+      burst[B_CUTS] += (unsigned long long)t_cuts;
+      burst[B_PROPS] += (unsigned long long)t_props;
+      burst[B_REVS] += (unsigned long long)t_revs;
+    }
   }
+}
+
+/* ---- device-driven iterations: what the host does around a small iteration, on the device ----
+ * cs_expand_burst = the head of one_iteration (how many parents, does it fit) + cs_expand_small; the pool top,
+ * the iteration budget and the running totals are in `burst`.  An iteration with nothing to do (pool empty,
+ * budget used up, ANY already solved, error) leaves zero children, and every later kernel of it returns at once. */
+__global__ __launch_bounds__(1024) void cs_expand_burst(const cs_val *__restrict__ pool, int n, csgpu_node *__restrict__ nodes,
+                                                        unsigned long long *__restrict__ counters,
+                                                        unsigned long long *__restrict__ burst, int objective,
+                                                        long long max_width, long long cap, long long room_limit) {
+  __shared__ int s_var[SMALL_PARENTS], s_cnt[SMALL_PARENTS], s_off[SMALL_PARENTS];
+  __shared__ long long s_part[16];
+  __shared__ long long s_first, s_iter;
+  __shared__ int s_parents;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) {
+    const long long top = (long long)burst[B_TOP];
+    /* a few parents while the pool is small (dive for a solution / an incumbent first), more once there is a
+     * backlog of open states: 1/16 of the pool, within [B_LIMIT, B_LIMIT_MAX] (schedule-10: 0.7 s instead of 1.6 s
+     * with 64 throughout; small searches lose a few ms) */
+    long long limit = top / 16;
+    limit = limit < (long long)burst[B_LIMIT] ? (long long)burst[B_LIMIT] : limit;
+    limit = limit > (long long)burst[B_LIMIT_MAX] ? (long long)burst[B_LIMIT_MAX] : limit;
+    long long parents = top < limit ? top : limit;
+    if (burst[B_BUDGET] == 0ull || burst[B_ERROR] != 0ull || (objective == CS_OBJ_ANY && counters[C_STORED] != 0ull))
+      parents = 0;
+    if (parents > 0 && top - parents + parents * max_width > room_limit) { /* as one_iteration */
+      const long long fit = max_width > 1 ? (room_limit - top) / (max_width - 1) : parents;
+      parents = fit < 1 ? 1 : (fit < parents ? fit : parents);
+      if (top - parents + parents * max_width > cap) {
+        burst[B_ERROR] = 1ull;
+        parents = 0;
+      }
+    }
+    s_parents = (int)parents;
+    s_first = top - parents;
+    s_iter = (long long)(burst[B_ITER_BASE] + burst[B_ITERS]);
+  }
+  if (threadIdx.x < C_PER_ITERATION) counters[threadIdx.x] = 0ull;
+  __syncthreads();
+  const int parents = s_parents;
+  if (parents == 0) return;
+  const long long first_row = s_first;
+  const int low_values_last = objective == CS_OBJ_MAX ? 0 : 1;
+  const unsigned scramble =
+      objective == CS_OBJ_ANY ? (unsigned)((unsigned long long)s_iter * 2654435761ull + 0x9e3779b9u) | 1u : 0u;
+  for (int p = wave; p < parents; p += 16) {
+    int var, count;
+    cs_branch_seg<64>(pool + (size_t)(first_row + p) * n, n, lane, &var, &count);
+    if (lane == 0) { s_var[p] = var; s_cnt[p] = count; }
+  }
+  __syncthreads();
+  long long total;
+  const int t = (int)threadIdx.x;
+  const long long ex = cs_block_excl_scan(t < parents ? (long long)s_cnt[t] : 0, s_part, &total);
+  if (t < parents) s_off[t] = (int)ex;
+  if (t == 0) {
+    counters[C_TOTAL_CHILDREN] = (unsigned long long)total;
+    burst[B_TOP] = (unsigned long long)first_row;
+    burst[B_ITERS] += 1ull;
+    burst[B_BUDGET] -= 1ull;
+    burst[B_NODES] += (unsigned long long)total;
+  }
+  __syncthreads();
+  for (int p = wave; p < parents; p += 16)
+    cs_emit_seg<64>(pool, first_row + p, n, s_var[p], s_off[p], s_cnt[p], nodes, low_values_last, scramble, lane);
+}
+
+/* cs_accept + cs_pick_best for the complete children of a small iteration, one workgroup, nothing read by the
+ * host: counts the solutions, moves the incumbent, keeps a state that attains it (and, ANY: the first one) */
+__global__ __launch_bounds__(256) void cs_accept_burst(const cs_val *__restrict__ child_states, const int *__restrict__ list,
+                                                       const int *__restrict__ truth, int n, int objective, int obj_var,
+                                                       unsigned long long *__restrict__ counters,
+                                                       unsigned long long *__restrict__ burst,
+                                                       int32_t *__restrict__ solutions, long long max_solutions,
+                                                       int32_t *__restrict__ best_solution) {
+  __shared__ long long s_key[256];
+  __shared__ int s_cnt[256];
+  __shared__ int s_pick;
+  const int count = (int)counters[C_COMPLETE];
+  if (count == 0) return;
+  const int t = (int)threadIdx.x;
+  const bool opt = objective == CS_OBJ_MIN || objective == CS_OBJ_MAX;
+  /* key: (objective value, made "smaller is better") << 32 | child index: the minimum is the best value and,
+   * among equals, the first child */
+  long long key = 0x7fffffffffffffffll;
+  int cnt = 0;
+  for (int i = t; i < count; i += 256) {
+    if (truth[i] != 1) continue;
+    cnt++;
+    long long val = 0;
+    if (opt) {
+      const cs_val o = child_states[(size_t)list[i] * n + obj_var];
+      val = objective == CS_OBJ_MIN ? (long long)o.lo : -(long long)o.hi;
+    }
+    const long long k = val * 4294967296ll + (long long)i;
+    key = k < key ? k : key;
+    if (objective != CS_OBJ_ANY && counters[C_STORED] < (unsigned long long)max_solutions) {
+      const unsigned long long slot = atomicAdd(&counters[C_STORED], 1ull);
+      if (slot < (unsigned long long)max_solutions)
+        for (int v = 0; v < n; v++) solutions[(size_t)slot * n + v] = child_states[(size_t)list[i] * n + v].lo;
+    }
+  }
+  s_key[t] = key;
+  s_cnt[t] = cnt;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) {
+    if (t < d) {
+      s_key[t] = s_key[t + d] < s_key[t] ? s_key[t + d] : s_key[t];
+      s_cnt[t] += s_cnt[t + d];
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    s_pick = -1;
+    const int accepted = s_cnt[0];
+    if (accepted > 0) {
+      const long long best_key = s_key[0];
+      const int idx = (int)(best_key & 0xffffffffll);
+      if (objective == CS_OBJ_ANY) {
+        /* found_any (csolve.c:207-209): exactly one solution is accepted, the first in child order */
+        if (counters[C_STORED] == 0ull) {
+          counters[C_SOLUTIONS] += 1ull;
+          counters[C_STORED] = 1ull;
+          s_pick = idx;
+        }
+      } else {
+        counters[C_SOLUTIONS] += (unsigned long long)accepted;
+        if (opt) {
+          const long long v = (best_key - (long long)idx) / 4294967296ll;
+          const int val = objective == CS_OBJ_MIN ? (int)v : (int)-v;
+          int *best = (int *)&counters[C_BEST];
+          if (objective == CS_OBJ_MIN ? val < *best : val > *best) {
+            *best = val;
+            burst[B_IMPROVED] = 1ull;
+            s_pick = idx;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int pick = s_pick;
+  if (pick < 0) return;
+  int32_t *out = objective == CS_OBJ_ANY ? solutions : best_solution;
+  for (int v = t; v < n; v += 256) out[v] = child_states[(size_t)list[pick] * n + v].lo;
 }
 
 /* copy survivor k (child surv_list[k]) into pool row new_top + k: a workgroup takes cpb (at most SB) consecutive
@@ -432,8 +600,10 @@ __global__ __launch_bounds__(SB) void cs_scatter(const cs_val *__restrict__ chil
                                                  const unsigned long long *__restrict__ counters, long long new_top, int n,
                                                  cs_val *__restrict__ pool,
                                                  const unsigned long long *__restrict__ child_forb,
-                                                 unsigned long long *__restrict__ pool_forb, int fw, int cpb) {
+                                                 unsigned long long *__restrict__ pool_forb, int fw, int cpb,
+                                                 const unsigned long long *__restrict__ new_top_dev) {
   __shared__ int s_src[SB];
+  if (new_top_dev != nullptr) new_top = (long long)*new_top_dev;
   const long long survivors = (long long)counters[C_SURVIVORS];
   const long long base = (long long)blockIdx.x * cpb;
   if (base >= survivors) return;
@@ -564,6 +734,10 @@ extern "C" void csgpu_search_free(csgpu_search *s) {
   (void)hipFree(s->d_counters); (void)hipFree(s->d_solutions);
   (void)hipFree(s->seed);
   (void)hipFree(s->d_best_solution);
+  (void)hipFree(s->d_burst);
+  if (s->h_burst) (void)hipHostFree(s->h_burst);
+  if (s->burst_exec) (void)hipGraphExecDestroy(s->burst_exec);
+  if (s->burst_stream) (void)hipStreamDestroy(s->burst_stream);
   free(s);
 }
 
@@ -600,6 +774,11 @@ extern "C" int csgpu_search_create(const csgpu_model *m, int64_t pool_capacity, 
   s->avg_children = (double)s->max_width;
   s->parents_limit = csgpu_model_objective(m) == CS_OBJ_ALL ? s->max_parents : 64;
   if (s->parents_limit > s->max_parents) s->parents_limit = s->max_parents;
+  s->parents_max = s->parents_limit;
+  if (csgpu_model_objective(m) == CS_OBJ_MIN || csgpu_model_objective(m) == CS_OBJ_MAX) { /* ANY stays depth-first */
+    s->parents_max = SMALL_PARENTS < s->max_parents ? SMALL_PARENTS : s->max_parents;
+    if (s->parents_max < s->parents_limit) s->parents_max = s->parents_limit;
+  }
   if (pool_capacity < max_children + 1) pool_capacity = max_children + 1;
   if (pool_capacity > 0x7fffffff) return fail(CSGPU_E_LIMIT, "pool_capacity too large");
   s->cap = pool_capacity;
@@ -651,6 +830,13 @@ extern "C" int csgpu_search_create(const csgpu_model *m, int64_t pool_capacity, 
 #undef ALLOC
   HIP_OK(hipMemset(s->d_counters, 0, sizeof(unsigned long long) * C_COUNT));
   HIP_OK(hipMemcpy(s->d_best, &s->st.best, sizeof(int), hipMemcpyHostToDevice));
+  HIP_OK(hipMalloc((void **)&s->d_burst, sizeof(unsigned long long) * B_COUNT));
+  HIP_OK(hipHostMalloc((void **)&s->h_burst, sizeof(unsigned long long) * (B_COUNT + C_COUNT), 0));
+  HIP_OK(hipStreamCreate(&s->burst_stream));
+  {
+    const char *e = getenv("CSGPU_SEARCH_BURST");
+    s->burst_off = e != NULL && e[0] == '0';
+  }
   *out = s;
   return CSGPU_OK;
 }
@@ -756,6 +942,7 @@ extern "C" int csgpu_search_take(csgpu_search *s, csgpu_val *d_states, int64_t m
 extern "C" int csgpu_search_set_parents(csgpu_search *s, int64_t parents_per_iteration) {
   if (s == NULL || parents_per_iteration < 1) return fail(CSGPU_E_ARG, "bad argument");
   s->parents_limit = parents_per_iteration < s->max_parents ? parents_per_iteration : s->max_parents;
+  s->parents_max = s->parents_limit; /* an explicit setting is taken literally */
   return CSGPU_OK;
 }
 
@@ -907,7 +1094,7 @@ static int one_iteration(csgpu_search *s) {
   const unsigned cb = (unsigned)((children + SB - 1) / SB);
   if (small) {
     hipLaunchKernelGGL(cs_classify_small, dim3(1), dim3(1024), 0, 0, s->d_results, s->d_dest, s->d_complete_list,
-                       s->d_counters);
+                       s->d_counters, (unsigned long long *)NULL);
   } else {
     hipLaunchKernelGGL(cs_classify_count, dim3(cb), dim3(SB), 0, 0, s->d_results, (int)children, s->d_block_surv,
                        s->d_block_comp, s->d_block_cuts, s->d_block_props, s->d_block_revs);
@@ -922,7 +1109,8 @@ static int one_iteration(csgpu_search *s) {
     cpb = cpb < 4 ? 4 : (cpb > SB ? SB : cpb);
     while (cpb > 4 && children / cpb < 2048) cpb >>= 1;
     hipLaunchKernelGGL(cs_scatter, dim3((unsigned)((children + cpb - 1) / cpb)), dim3(SB), 0, 0, s->d_child_states, s->d_dest,
-                       s->d_counters, (long long)s->top, n, s->pool, s->d_child_forb, s->pool_forb, s->fw, cpb);
+                       s->d_counters, (long long)s->top, n, s->pool, s->d_child_forb, s->pool_forb, s->fw, cpb,
+                       (const unsigned long long *)NULL);
   }
   /* the (only, for a small iteration) host read: class counts, the real number of children, and what the
    * previous iteration's accept left behind */
@@ -962,16 +1150,144 @@ static int one_iteration(csgpu_search *s) {
   return CSGPU_OK;
 }
 
+/* ---- device-driven iterations (ANY / MIN / MAX) ----
+ * These searches expand a few parents per iteration (depth first towards a solution / a better incumbent), so an
+ * iteration is a handful of small launches and, driven from the host, mostly the round trip for its counts.
+ * Here BURST_ITERATIONS iterations are enqueued at once -- as one hipGraph, built once -- with everything the host
+ * would decide in between (how many parents, where the survivors go, the incumbent, whether to stop) decided by
+ * single-workgroup kernels from state in device memory; the host reads the totals once per burst. */
+static int burst_applicable(const csgpu_search *s) {
+  return !s->burst_off && s->objective != CS_OBJ_ALL && s->parents_max <= SMALL_PARENTS &&
+         s->parents_max * s->max_width <= s->max_children;
+}
+
+static int enqueue_burst(csgpu_search *s, hipStream_t st) {
+  const int n = s->n;
+  const int64_t bound = s->parents_max * s->max_width; /* children of one iteration at most */
+  const int64_t reserve = (int64_t)s->n * s->max_width;
+  const long long room_limit = s->cap > reserve ? s->cap - reserve : s->cap;
+  const uint64_t *d_children = (const uint64_t *)(s->d_counters + C_TOTAL_CHILDREN);
+  const int sense = s->objective == CS_OBJ_MIN ? 1 : (s->objective == CS_OBJ_MAX ? 2 : 0);
+  int cpb = 4096 / n;
+  cpb = cpb < 4 ? 4 : (cpb > SB ? SB : cpb);
+  while (cpb > 4 && bound / cpb < 2048) cpb >>= 1;
+  for (int it = 0; it < BURST_ITERATIONS; it++) {
+    hipLaunchKernelGGL(cs_expand_burst, dim3(1), dim3(1024), 0, st, s->pool, n, s->d_nodes, s->d_counters, s->d_burst,
+                       s->objective, (long long)s->max_width, (long long)s->cap, room_limit);
+    int rc;
+    if (s->fw > 0)
+      rc = csgpu_internal_propagate_fb(s->m, (const csgpu_val *)s->pool, (const uint64_t *)s->pool_forb, s->d_nodes,
+                                       (csgpu_val *)s->d_child_states, (uint64_t *)s->d_child_forb, s->d_results, bound,
+                                       d_children, st);
+    else
+      rc = csgpu_internal_propagate_objdev(s->m, (const csgpu_val *)s->pool, s->d_nodes, (csgpu_val *)s->d_child_states,
+                                           s->d_results, bound, d_children, CS_DOM_MIN, CS_DOM_MAX,
+                                           sense ? (const int32_t *)s->d_best : NULL, sense, st);
+    if (rc != CSGPU_OK) return rc;
+    hipLaunchKernelGGL(cs_classify_small, dim3(1), dim3(1024), 0, st, s->d_results, s->d_dest, s->d_complete_list,
+                       s->d_counters, s->d_burst);
+    hipLaunchKernelGGL(cs_scatter, dim3((unsigned)((bound + cpb - 1) / cpb)), dim3(SB), 0, st, s->d_child_states, s->d_dest,
+                       s->d_counters, 0ll, n, s->pool, s->d_child_forb, s->pool_forb, s->fw, cpb,
+                       (const unsigned long long *)(s->d_burst + B_SCATTER_BASE));
+    rc = csgpu_internal_eval_list(s->m, (const csgpu_val *)s->d_child_states, s->d_complete_list,
+                                  (const uint64_t *)(s->d_counters + C_COMPLETE), bound, s->d_truth, st);
+    if (rc != CSGPU_OK) return rc;
+    hipLaunchKernelGGL(cs_accept_burst, dim3(1), dim3(256), 0, st, s->d_child_states, s->d_complete_list, s->d_truth, n,
+                       s->objective, s->obj_var, s->d_counters, s->d_burst, s->d_solutions, (long long)s->max_solutions,
+                       s->d_best_solution);
+  }
+  HIP_OK(hipGetLastError());
+  return CSGPU_OK;
+}
+
+/* up to `budget` iterations; *done = how many had parents */
+static int run_burst(csgpu_search *s, int64_t budget, int64_t *done) {
+  int rc = flush_accept_results(s);
+  if (rc != CSGPU_OK) return rc;
+  static int graphs_off = -1;
+  if (graphs_off < 0) {
+    const char *e = getenv("CSGPU_SEARCH_GRAPH");
+    graphs_off = e != NULL && e[0] == '0';
+  }
+  if (!graphs_off && (s->burst_exec == NULL || s->burst_limit != s->parents_max)) {
+    if (s->burst_exec != NULL) {
+      (void)hipGraphExecDestroy(s->burst_exec);
+      s->burst_exec = NULL;
+    }
+    hipGraph_t graph = NULL;
+    if (hipStreamBeginCapture(s->burst_stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+      rc = enqueue_burst(s, s->burst_stream);
+      const hipError_t e = hipStreamEndCapture(s->burst_stream, &graph);
+      if (rc != CSGPU_OK) {
+        if (graph != NULL) (void)hipGraphDestroy(graph);
+        return rc;
+      }
+      if (e == hipSuccess && graph != NULL && hipGraphInstantiate(&s->burst_exec, graph, NULL, NULL, 0) != hipSuccess)
+        s->burst_exec = NULL;
+      if (graph != NULL) (void)hipGraphDestroy(graph);
+    }
+    (void)hipGetLastError();
+    s->burst_limit = s->parents_max;
+  }
+  unsigned long long *h = s->h_burst;
+  memset(h, 0, sizeof(unsigned long long) * B_COUNT);
+  h[B_TOP] = (unsigned long long)s->top;
+  h[B_BUDGET] = (unsigned long long)(budget < BURST_ITERATIONS ? budget : BURST_ITERATIONS);
+  h[B_LIMIT] = (unsigned long long)s->parents_limit;
+  h[B_LIMIT_MAX] = (unsigned long long)s->parents_max;
+  h[B_ITER_BASE] = (unsigned long long)s->st.iterations;
+  h[B_PEAK] = (unsigned long long)s->peak;
+  HIP_OK(hipMemcpyAsync(s->d_burst, h, sizeof(unsigned long long) * B_COUNT, hipMemcpyHostToDevice, s->burst_stream));
+  if (s->burst_exec != NULL) {
+    HIP_OK(hipGraphLaunch(s->burst_exec, s->burst_stream));
+  } else {
+    rc = enqueue_burst(s, s->burst_stream);
+    if (rc != CSGPU_OK) return rc;
+  }
+  HIP_OK(hipMemcpyAsync(h, s->d_burst, sizeof(unsigned long long) * B_COUNT, hipMemcpyDeviceToHost, s->burst_stream));
+  HIP_OK(hipMemcpyAsync(h + B_COUNT, s->d_counters, sizeof(unsigned long long) * C_COUNT, hipMemcpyDeviceToHost,
+                        s->burst_stream));
+  HIP_OK(hipStreamSynchronize(s->burst_stream));
+  if (h[B_ERROR] != 0ull) return fail(CSGPU_E_LIMIT, "state pool is full");
+  *done = (int64_t)h[B_ITERS];
+  s->top = (int64_t)h[B_TOP];
+  s->peak = (int64_t)h[B_PEAK];
+  s->st.iterations += h[B_ITERS];
+  s->st.nodes += h[B_NODES];
+  s->st.cuts += h[B_CUTS];
+  s->st.props += h[B_PROPS];
+  s->st.revisions += h[B_REVS];
+  s->st.solutions = h[B_COUNT + C_SOLUTIONS];
+  if (s->objective == CS_OBJ_MIN || s->objective == CS_OBJ_MAX) s->st.best = (int)(unsigned)h[B_COUNT + C_BEST];
+  if (h[B_IMPROVED] != 0ull) s->have_best_solution = 1;
+  return CSGPU_OK;
+}
+
 extern "C" int csgpu_search_run(csgpu_search *s, int64_t max_iterations, csgpu_search_stats *stats) {
   if (s == NULL || stats == NULL) return fail(CSGPU_E_ARG, "bad argument");
   for (int64_t it = 0; it < max_iterations; it++) {
     if (s->top == 0) break;
     if (s->objective == CS_OBJ_ANY && s->st.solutions > 0) break;
-    int rc = one_iteration(s);
-    if (rc != CSGPU_OK) return rc;
+    int rc;
+    int64_t steps = 1; /* iterations this pass of the loop made */
+    const int restarts_on = s->restart_base > 0 && s->seed_count > 0 && s->st.solutions == 0;
+    if (burst_applicable(s)) {
+      int64_t budget = max_iterations - it;
+      if (restarts_on) { /* stop where check_restart would fire */
+        const int64_t until = (int64_t)s->luby_threshold * s->restart_base + 1 - s->since_restart;
+        if (until < budget) budget = until < 1 ? 1 : until;
+      }
+      rc = run_burst(s, budget, &steps);
+      if (rc != CSGPU_OK) return rc;
+      if (steps == 0) break; /* nothing left to expand (or ANY solved) */
+      it += steps - 1;
+    } else {
+      rc = one_iteration(s);
+      if (rc != CSGPU_OK) return rc;
+    }
     /* check_restart (csolve.c:264-276) with Knuth's Luby sequence (csolve.c:76-83) */
-    if (s->restart_base > 0 && s->seed_count > 0 && s->st.solutions == 0 &&
-        ++s->since_restart > (int64_t)s->luby_threshold * s->restart_base) {
+    if (restarts_on && s->st.solutions == 0 &&
+        (s->since_restart += steps) > (int64_t)s->luby_threshold * s->restart_base) {
       s->since_restart = 0;
       if ((s->luby_counter & (0 - s->luby_counter)) == s->luby_threshold) {
         s->luby_counter++;

@@ -1,5 +1,7 @@
-import sys, time, torch
-sys.path.insert(0, ".")
+import os, sys, time, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.chdir(ROOT)
 from csolve_amd import problems
 from csolve_amd.solver import Search, solve_root
 for name, text in (("ref_wcet", open("tests/golden/problems/ref_wcet.txt").read()),

@@ -63,7 +63,8 @@ struct csgpu_search {
   hipStream_t burst_stream;
   hipGraphExec_t burst_exec;
   int64_t burst_limit; /* parents per iteration the graph was built for (0: none) */
-  int burst_off;       /* CSGPU_SEARCH_BURST=0 */
+  int burst_off;       /* CSGPU_SEARCH_BURST=0: every iteration driven from the host */
+  int graph_off;       /* CSGPU_SEARCH_GRAPH=0: the launches of a burst enqueued one by one */
 };
 
 extern "C" int csgpu_internal_set_error(int code, const char *msg); /* cs_capi.hip */
@@ -836,6 +837,8 @@ extern "C" int csgpu_search_create(const csgpu_model *m, int64_t pool_capacity, 
   {
     const char *e = getenv("CSGPU_SEARCH_BURST");
     s->burst_off = e != NULL && e[0] == '0';
+    e = getenv("CSGPU_SEARCH_GRAPH");
+    s->graph_off = e != NULL && e[0] == '0';
   }
   *out = s;
   return CSGPU_OK;
@@ -1204,12 +1207,7 @@ static int enqueue_burst(csgpu_search *s, hipStream_t st) {
 static int run_burst(csgpu_search *s, int64_t budget, int64_t *done) {
   int rc = flush_accept_results(s);
   if (rc != CSGPU_OK) return rc;
-  static int graphs_off = -1;
-  if (graphs_off < 0) {
-    const char *e = getenv("CSGPU_SEARCH_GRAPH");
-    graphs_off = e != NULL && e[0] == '0';
-  }
-  if (!graphs_off && (s->burst_exec == NULL || s->burst_limit != s->parents_max)) {
+  if (!s->graph_off && (s->burst_exec == NULL || s->burst_limit != s->parents_max)) {
     if (s->burst_exec != NULL) {
       (void)hipGraphExecDestroy(s->burst_exec);
       s->burst_exec = NULL;

@@ -194,3 +194,40 @@ def test_small_pools_still_walk_the_whole_tree(pool, children):
     from csolve_amd import problems
     model, s, st = _solve(problems.queens(10, "ALL"), pool=pool, children=children)
     assert st["done"] == 1 and st["solutions"] == 724 and st["pool_peak"] <= max(pool, children + 1)
+
+
+@pytest.mark.parametrize("name,best", [("ref_schedule", 11), ("schedule6_s1", 22), ("ref_wcet", 1560)])
+def test_device_driven_iterations_equal_host_driven_ones(name, best, monkeypatch):
+    """ANY / MIN / MAX iterations are enqueued sixteen at a time with the bookkeeping on the device (one hipGraph);
+    CSGPU_SEARCH_BURST=0 drives every iteration from the host and CSGPU_SEARCH_GRAPH=0 enqueues the launches one
+    by one: same optimum and a valid solution every way, and an iteration budget that is not a multiple of
+    sixteen is kept exactly."""
+    from csolve_amd.solver import Search, solve_root
+    text = open(golden("problems", name + ".txt")).read()
+    model = solve_root(text)
+    stats = {}
+    for mode, env in (("graph", {}), ("launches", {"CSGPU_SEARCH_GRAPH": "0"}), ("host", {"CSGPU_SEARCH_BURST": "0"})):
+        monkeypatch.delenv("CSGPU_SEARCH_GRAPH", raising=False)
+        monkeypatch.delenv("CSGPU_SEARCH_BURST", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        s = Search(model, 1 << 20, 1 << 16)
+        s.set_parents(64)  # the same batches in every mode
+        s.put(model.root_state())
+        iterations = 0
+        for _ in range(1000000):
+            before = iterations
+            st = s.run(21)
+            iterations = st["iterations"]
+            assert iterations - before <= 21
+            if st["done"]:
+                break
+        assert st["done"] == 1 and st["best"] == best, mode
+        row = s.best_solution()
+        assert row is not None and row[model.objective_var] == best
+        truth = model.eval_root(torch.from_numpy(np.stack([row, row], 1)[None].astype(np.int32)).cuda())
+        assert int(truth[0]) == 1
+        stats[mode] = st
+    assert stats["graph"] == stats["launches"]  # the graph is only a way of launching
+    # the host-driven loop learns of a new incumbent one iteration later, so it may expand a few more nodes
+    assert stats["host"]["nodes"] >= stats["graph"]["nodes"]

@@ -237,7 +237,8 @@ int csgpu_search_put_host(csgpu_search *s, const csgpu_val *states, int64_t coun
 int csgpu_search_take(csgpu_search *s, csgpu_val *d_states, int64_t max, int64_t *count);
 /* cap on the open states expanded per iteration (default: as many as max_children allows for
  * ALL; 64 for ANY/MIN/MAX, which makes the walk depth-first enough to reach a first solution or a
- * good incumbent early with a small pool) */
+ * good incumbent early with a small pool; MIN/MAX go up to 256 while the pool holds a backlog of
+ * more than 16 x as many open states).  A value set here is taken literally. */
 int csgpu_search_set_parents(csgpu_search *s, int64_t parents_per_iteration);
 /* ANY only: restart from the seeded states after luby(i) x `iterations` iterations without a
  * solution (the reference restarts after luby(i) x restart_frequency failures, csolve.c:76-83,
@@ -246,7 +247,11 @@ int csgpu_search_set_parents(csgpu_search *s, int64_t parents_per_iteration);
 int csgpu_search_set_restart(csgpu_search *s, int64_t iterations);
 /* merge an incumbent found elsewhere (objective_best of the shared page, objective.c:89-93) */
 int csgpu_search_set_best(csgpu_search *s, int32_t best);
-/* run up to max_iterations iterations (stops early when done) */
+/* run up to max_iterations iterations (stops early when done).  ANY/MIN/MAX iterations are enqueued
+ * sixteen at a time as one hipGraph with the bookkeeping between them on the device (pool top, child
+ * counts, incumbent, stop conditions); the host reads the totals once per sixteen.  Environment, read
+ * at csgpu_search_create: CSGPU_SEARCH_BURST=0 drives every iteration from the host,
+ * CSGPU_SEARCH_GRAPH=0 enqueues the launches one by one instead of as a graph. */
 int csgpu_search_run(csgpu_search *s, int64_t max_iterations, csgpu_search_stats *stats);
 /* copy up to `max` stored solutions ([k][n_vars] values, host memory); returns k */
 int64_t csgpu_search_solutions(const csgpu_search *s, int32_t *values, int64_t max);

@@ -41,6 +41,27 @@ def queens(n: int, objective: str = "ANY") -> str:
     return "\n".join(lines) + "\n"
 
 
+def offsets(n: int = 20, values: int = 48, seed: int = 1, objective: str = "ANY") -> str:
+    """A small binary != network with irregular shape: n variables of `values` values each, every variable
+    with its own lower bound, and for most pairs one or two constraints Vi != Vj + d with seeded offsets
+    (neither queens' three-per-pair regularity nor a common window: exercises the general table layout
+    of the forbidden-set kernels and windows of more than 32 values on small models)."""
+    rng = LCG(seed * 7919 + n * 31 + values)
+    lo = [rng.below(9) - 4 for _ in range(n)]
+    lines = [f"# offsets network, {n} variables x {values} values, seed {seed}", f"{objective};"]
+    for i in range(n):
+        for j in range(i + 1, n):
+            k = rng.below(4)  # 0: unrelated, 1: one constraint, 2-3: two constraints
+            ds = set()
+            for _ in range(min(k, 2)):
+                ds.add(rng.below(2 * values // 3 + 1) - values // 3 + lo[i] - lo[j])
+            for d in sorted(ds):
+                lines.append(f"V{i + 1} != V{j + 1} {'+' if d >= 0 else '-'} {abs(d)};")
+    for i in range(n):
+        lines.append(f"{lo[i]} <= V{i + 1}; V{i + 1} <= {lo[i] + values - 1};")
+    return "\n".join(lines) + "\n"
+
+
 def _cell(r: int, c: int) -> str:
     return f"C{r}_{c}"
 

@@ -18,6 +18,17 @@ WALKS_WITH_MODEL = sorted(os.path.basename(p)[:-8] for p in glob.glob(golden("wa
                           if os.path.exists(golden("models", os.path.basename(p)[:-8] + ".model")))
 
 
+def _text(kind, size):
+    from csolve_amd import problems
+    if kind == "queens":
+        return problems.queens(size)
+    if kind == "sudoku":
+        return problems.sudoku(size, 0.4, 1)
+    if kind.startswith("offsets"):  # offsets48: 48 values per variable
+        return problems.offsets(size, int(kind[7:]), 1)
+    raise ValueError(kind)
+
+
 def _kernels(model):
     """every kernel that can run this model: 1 = general, 2 = LDS-resident (when it qualifies)"""
     ks = [1]
@@ -233,7 +244,9 @@ def test_propagate_one_host_path():
 @pytest.mark.parametrize("kind,size,kernel", [("queens", 16, 3), ("queens", 64, 3), ("queens", 128, 3), ("sudoku", 3, 3),
                                               ("sudoku", 5, 3), ("queens", 16, 4), ("queens", 64, 4), ("queens", 128, 4),
                                               ("queens", 100, 4), ("sudoku", 3, 4), ("sudoku", 4, 4),
-                                              ("queens", 16, 5), ("queens", 13, 5), ("queens", 17, 5), ("queens", 32, 5)])
+                                              ("queens", 16, 5), ("queens", 13, 5), ("queens", 17, 5), ("queens", 32, 5),
+                                              ("offsets48", 20, 5), ("offsets48", 12, 5), ("offsets24", 30, 5),
+                                              ("offsets48", 20, 4), ("offsets40", 40, 4), ("offsets48", 20, 3)])
 def test_forbidden_sets_inherited_down_a_path(kind, size, kernel):
     """The forbidden-set kernel with the sets carried from parent to child (the search engine's
     mode) against the general kernel and the oracle, five levels deep: same verdicts, same
@@ -241,7 +254,7 @@ def test_forbidden_sets_inherited_down_a_path(kind, size, kernel):
     from csolve_amd import problems
     from csolve_amd.solver import solve_root
     from oracle.cs_oracle import Model as OModel, Oracle
-    text = problems.queens(size) if kind == "queens" else problems.sudoku(size, 0.4, 1)
+    text = _text(kind, size)
     model = solve_root(text)
     fw = model.forbidden_words()
     assert fw > 0
@@ -295,7 +308,8 @@ def test_forbidden_sets_inherited_down_a_path(kind, size, kernel):
 
 @pytest.mark.parametrize("kind,size,count", [("queens", 64, 1 << 17), ("queens", 128, 1 << 16), ("queens", 100, 1 << 15),
                                              ("sudoku", 4, 1 << 15), ("sudoku", 3, 1 << 15),
-                                             ("queens", 16, (1 << 17) + 3), ("queens", 30, (1 << 16) + 1)])
+                                             ("queens", 16, (1 << 17) + 3), ("queens", 30, (1 << 16) + 1),
+                                             ("offsets48", 20, (1 << 16) + 2), ("offsets24", 14, 1 << 16)])
 def test_large_batches_agree_across_kernels(kind, size, count):
     """Batches large enough that every wave walks through several chunks of nodes under full load
     (the small parity batches give each wave at most one chunk): the forbidden-set kernels with
@@ -305,7 +319,7 @@ def test_large_batches_agree_across_kernels(kind, size, count):
     import bench
     from csolve_amd import problems
     from csolve_amd.solver import solve_root
-    text = problems.queens(size) if kind == "queens" else problems.sudoku(size, 0.4, 1)
+    text = _text(kind, size)
     model = solve_root(text)
     assert model.forbidden_words() > 0
     states_in, nodes, forb_in = bench.make_instances(model, count, seed=99, walks=4096, with_sets=True, restore_kernel=3)

@@ -1246,6 +1246,10 @@ static int run_burst(csgpu_search *s, int64_t budget, int64_t *done) {
   HIP_OK(hipMemcpyAsync(h + B_COUNT, s->d_counters, sizeof(unsigned long long) * C_COUNT, hipMemcpyDeviceToHost,
                         s->burst_stream));
   HIP_OK(hipStreamSynchronize(s->burst_stream));
+  if (getenv("CSGPU_SEARCH_TRACE") != NULL)
+    fprintf(stderr, "burst: iters %llu top %llu nodes %llu cuts %llu | surv %llu complete %llu children %llu solutions %llu stored %llu best %d\n",
+            h[B_ITERS], h[B_TOP], h[B_NODES], h[B_CUTS], h[B_COUNT + C_SURVIVORS], h[B_COUNT + C_COMPLETE],
+            h[B_COUNT + C_TOTAL_CHILDREN], h[B_COUNT + C_SOLUTIONS], h[B_COUNT + C_STORED], (int)(unsigned)h[B_COUNT + C_BEST]);
   if (h[B_ERROR] != 0ull) return fail(CSGPU_E_LIMIT, "state pool is full");
   *done = (int64_t)h[B_ITERS];
   s->top = (int64_t)h[B_TOP];

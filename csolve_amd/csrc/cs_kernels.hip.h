@@ -378,6 +378,8 @@ __global__ __launch_bounds__(CS_BLOCK) void cs_propagate_events(cs_tables T, con
   const int n = T.n_vars, nw = T.n_words;
   /* the search engine launches for an upper bound and leaves the real count on the device */
   if (batch_dev != nullptr && (long long)*batch_dev < batch) batch = (long long)*batch_dev;
+  /* a workgroup without a node (launch sized for the upper bound) must not pay for the table copy below */
+  if ((long long)blockIdx.x * CS_WAVES_PER_BLOCK >= batch) return;
   /* tables (TAB_LDS): adj_off[n+1] | adj[n_adj] | lit[n_lits], each padded to 16 bytes */
   const int n_adj = TAB_LDS ? T.adj_off[n] : 0;
   const size_t off_bytes = TAB_LDS ? ((((size_t)n + 1) * sizeof(int) + 15) & ~(size_t)15) : 0;
@@ -764,6 +766,7 @@ __global__ __launch_bounds__(1024, (FW <= 1 && R <= 1 ? 8 : 4)) void cs_propagat
   const int waves_per_block = blockDim.x >> 6;
   const int n = T.n_vars, nw = T.n_words;
   if (batch_dev != nullptr && (long long)*batch_dev < batch) batch = (long long)*batch_dev;
+  if ((long long)blockIdx.x * waves_per_block * csz >= batch) return; /* no node for this workgroup: skip the table copy */
   /* LDS: {begin,end}[n] | root_lo[n] | packed adjacency | per wave: domains, sets, two masks, counter */
   int2 *s_off2 = (int2 *)cs_lds;
   const size_t off_bytes = (((size_t)n * sizeof(int2)) + 15) & ~(size_t)15;
@@ -1120,6 +1123,7 @@ __global__ __launch_bounds__(1024, (FW * R <= 1 ? 8 : 4)) void cs_propagate_ne_r
   const int lane = threadIdx.x & (CS_WAVE - 1);
   const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); /* keeps row addresses scalar */
   const int waves_per_block = blockDim.x >> 6;
+  if ((long long)blockIdx.x * waves_per_block * csz >= batch) return; /* no node for this workgroup: skip the table copy */
   E *s_tab = (E *)cs_lds;
   {
     const int vecs = (int)(((size_t)n * slots * W * sizeof(E)) / 16); /* W is a multiple of 64 */
@@ -1431,6 +1435,7 @@ __global__ __launch_bounds__(1024, 8) void cs_propagate_ne_packed(
   const int lane = threadIdx.x & (CS_WAVE - 1);
   const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int waves_per_block = blockDim.x >> 6;
+  if ((long long)blockIdx.x * waves_per_block * G >= batch) return; /* no node for this workgroup: skip the table copy */
   unsigned short *s_tab = (unsigned short *)cs_lds;
   {
     const int vecs = (int)(((size_t)n * slots * W * 2) / 16);

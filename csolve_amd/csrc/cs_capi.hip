@@ -963,17 +963,29 @@ extern "C" int csgpu_internal_propagate_objdev(const csgpu_model *m, const csgpu
   return CSGPU_OK;
 }
 
+/* one wave per state while four domain arrays fit 64 KB of LDS, else one workgroup per state */
+static int launch_eval_root(const csgpu_model *m, const csgpu_val *d_states, const int32_t *d_list, const uint64_t *d_count,
+                            int64_t count, int32_t *d_truth, void *stream) {
+  const size_t row = (size_t)m->host->n_vars * sizeof(cs_val);
+  if (row * CS_WAVES_PER_BLOCK <= 64u * 1024u) {
+    hipLaunchKernelGGL(cs_eval_root_waves, dim3((unsigned)((count + CS_WAVES_PER_BLOCK - 1) / CS_WAVES_PER_BLOCK)),
+                       dim3(CS_BLOCK), row * CS_WAVES_PER_BLOCK, (hipStream_t)stream, m->tab, (const cs_val *)d_states, d_truth,
+                       (const int *)d_list, (const unsigned long long *)d_count, (long long)count);
+  } else {
+    hipLaunchKernelGGL(cs_eval_root, dim3((unsigned)count), dim3(CS_BLOCK), row + 16, (hipStream_t)stream, m->tab,
+                       (const cs_val *)d_states, d_truth, (const int *)d_list, (const unsigned long long *)d_count);
+  }
+  HIP_TRY(hipGetLastError());
+  return CSGPU_OK;
+}
+
 extern "C" int csgpu_eval_batch(const csgpu_model *m, const csgpu_val *d_states, int32_t *d_truth, int64_t batch,
                                 void *stream) {
   if (m == NULL || d_states == NULL || d_truth == NULL || batch < 0) return set_err(CSGPU_E_ARG, "null argument");
   if (!m->finalized) return set_err(CSGPU_E_STATE, "model is not finalized");
   if (batch == 0) return CSGPU_OK;
   if (batch > 0x7fffffff) return set_err(CSGPU_E_LIMIT, "batch too large");
-  const size_t lds = (size_t)m->host->n_vars * sizeof(cs_val) + 16;
-  hipLaunchKernelGGL(cs_eval_root, dim3((unsigned)batch), dim3(CS_BLOCK), lds, (hipStream_t)stream, m->tab,
-                     (const cs_val *)d_states, d_truth, (const int *)NULL, (const unsigned long long *)NULL);
-  HIP_TRY(hipGetLastError());
-  return CSGPU_OK;
+  return launch_eval_root(m, d_states, NULL, NULL, batch, d_truth, stream);
 }
 
 /* instance i = row d_list[i] of d_states, i < *d_count <= bound (the count stays on the device) */
@@ -984,11 +996,7 @@ extern "C" int csgpu_internal_eval_list(const csgpu_model *m, const csgpu_val *d
   if (!m->finalized) return set_err(CSGPU_E_STATE, "model is not finalized");
   if (bound == 0) return CSGPU_OK;
   if (bound > 0x7fffffff) return set_err(CSGPU_E_LIMIT, "batch too large");
-  const size_t lds = (size_t)m->host->n_vars * sizeof(cs_val) + 16;
-  hipLaunchKernelGGL(cs_eval_root, dim3((unsigned)bound), dim3(CS_BLOCK), lds, (hipStream_t)stream, m->tab,
-                     (const cs_val *)d_states, d_truth, (const int *)d_list, (const unsigned long long *)d_count);
-  HIP_TRY(hipGetLastError());
-  return CSGPU_OK;
+  return launch_eval_root(m, d_states, d_list, d_count, bound, d_truth, stream);
 }
 
 extern "C" int csgpu_eval_clauses(const csgpu_model *m, const csgpu_val *d_state, csgpu_val *d_vals, void *stream) {

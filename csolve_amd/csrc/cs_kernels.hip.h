@@ -1649,6 +1649,60 @@ __global__ __launch_bounds__(CS_BLOCK) void cs_propagate_sweeps(cs_tables T, con
 
 /* ---- three-valued evaluation of the root wide-and (eval.c:233-255) ---------------- */
 
+/* interval value of clause c on the domains `dom` (eval_<op> of the clause's root) */
+__device__ __forceinline__ cs_val cs_eval_clause(const cs_tables &T, int c, const cs_val *dom) {
+  const int4 rec = T.clause[c];
+  cs_val v = cs_value(1);
+  if (rec.x == CS_CL_NE) {
+    /* NOT(EQ(X_a, X_b + d)); no saturation possible on this path (cs_device.h) */
+    cs_val a = dom[rec.y], b = dom[rec.z];
+    b.lo += rec.w;
+    b.hi += rec.w;
+    v = cs_ev_not(cs_ev_eq(a, b));
+  } else if (rec.x == CS_CL_EQ || rec.x == CS_CL_LT) {
+    v = rec.x == CS_CL_EQ ? cs_ev_eq_shifted(dom[rec.y], dom[rec.z], rec.w) : cs_ev_lt_shifted(dom[rec.y], dom[rec.z], rec.w);
+  } else if (rec.x == CS_CL_OR2) {
+    cs_val t[2];
+    for (int k = 0; k < 2; k++) {
+      const int4 l = T.lit[rec.y + k];
+      t[k] = cs_ev_lt_shifted(dom[l.x], dom[l.y], l.z);
+    }
+    v = cs_ev_or(t[0], t[1]);
+  } else if (rec.x == CS_CL_TREE) {
+    cs_tree_scratch S;
+    const int base = T.tree_off[rec.y], len = T.tree_off[rec.y + 1] - base;
+    cs_tree_eval(T, T.tnode + base, len, dom, S.val);
+    v = S.val[len - 1];
+  }
+  return v;
+}
+
+/* one WAVE per state (models whose domains fit a quarter of the LDS budget): no workgroup barrier, four states
+ * per workgroup.  list / count_dev as below. */
+__global__ __launch_bounds__(CS_BLOCK) void cs_eval_root_waves(cs_tables T, const cs_val *__restrict__ states,
+                                                               int *__restrict__ truth, const int *__restrict__ list,
+                                                               const unsigned long long *__restrict__ count_dev,
+                                                               long long count) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
+  const int n = T.n_vars;
+  const int lane = threadIdx.x & (CS_WAVE - 1), wave_in_block = threadIdx.x >> 6;
+  if (count_dev != nullptr && (long long)*count_dev < count) count = (long long)*count_dev;
+  const long long inst = (long long)blockIdx.x * CS_WAVES_PER_BLOCK + wave_in_block;
+  if (inst >= count) return;
+  cs_val *dom = (cs_val *)cs_lds + (size_t)wave_in_block * n;
+  const cs_val *src = states + (size_t)(list != nullptr ? list[inst] : inst) * n;
+  for (int v = lane; v < n; v += CS_WAVE) dom[v] = src[v];
+  cs_wave_sync();
+  int any_false = 0, any_open = 0;
+  for (int c = lane; c < T.n_clauses; c += CS_WAVE) {
+    const cs_val v = cs_eval_clause(T, c, dom);
+    any_false |= cs_is_false(v);
+    any_open |= !cs_is_false(v) && !cs_is_true(v);
+  }
+  const bool f = __any(any_false), o = __any(any_open);
+  if (lane == 0) truth[inst] = f ? 0 : (o ? 2 : 1);
+}
+
 /* list (nullable): instance i is row list[i] of states; count_dev (nullable): the number of instances, on the
  * device (the grid is then sized for an upper bound) */
 __global__ __launch_bounds__(CS_BLOCK) void cs_eval_root(cs_tables T, const cs_val *__restrict__ states,
@@ -1666,29 +1720,7 @@ __global__ __launch_bounds__(CS_BLOCK) void cs_eval_root(cs_tables T, const cs_v
   __syncthreads();
   int any_false = 0, any_open = 0;
   for (int c = threadIdx.x; c < T.n_clauses; c += blockDim.x) {
-    const int4 rec = T.clause[c];
-    cs_val v = cs_value(1);
-    if (rec.x == CS_CL_NE) {
-      /* NOT(EQ(X_a, X_b + d)); no saturation possible on this path (cs_device.h) */
-      cs_val a = dom[rec.y], b = dom[rec.z];
-      b.lo += rec.w;
-      b.hi += rec.w;
-      v = cs_ev_not(cs_ev_eq(a, b));
-    } else if (rec.x == CS_CL_EQ || rec.x == CS_CL_LT) {
-      v = rec.x == CS_CL_EQ ? cs_ev_eq_shifted(dom[rec.y], dom[rec.z], rec.w) : cs_ev_lt_shifted(dom[rec.y], dom[rec.z], rec.w);
-    } else if (rec.x == CS_CL_OR2) {
-      cs_val t[2];
-      for (int k = 0; k < 2; k++) {
-        const int4 l = T.lit[rec.y + k];
-        t[k] = cs_ev_lt_shifted(dom[l.x], dom[l.y], l.z);
-      }
-      v = cs_ev_or(t[0], t[1]);
-    } else if (rec.x == CS_CL_TREE) {
-      cs_tree_scratch S;
-      const int base = T.tree_off[rec.y], len = T.tree_off[rec.y + 1] - base;
-      cs_tree_eval(T, T.tnode + base, len, dom, S.val);
-      v = S.val[len - 1];
-    }
+    const cs_val v = cs_eval_clause(T, c, dom);
     any_false |= cs_is_false(v);
     any_open |= !cs_is_false(v) && !cs_is_true(v);
   }
@@ -1707,29 +1739,7 @@ __global__ __launch_bounds__(CS_BLOCK) void cs_eval_clauses(cs_tables T, const c
   for (int v = threadIdx.x; v < n; v += blockDim.x) dom[v] = state[v];
   __syncthreads();
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < T.n_clauses; c += gridDim.x * blockDim.x) {
-    const int4 rec = T.clause[c];
-    cs_val v = cs_value(1);
-    if (rec.x == CS_CL_NE) {
-      cs_val a = dom[rec.y], b = dom[rec.z];
-      b.lo += rec.w;
-      b.hi += rec.w;
-      v = cs_ev_not(cs_ev_eq(a, b));
-    } else if (rec.x == CS_CL_EQ || rec.x == CS_CL_LT) {
-      v = rec.x == CS_CL_EQ ? cs_ev_eq_shifted(dom[rec.y], dom[rec.z], rec.w) : cs_ev_lt_shifted(dom[rec.y], dom[rec.z], rec.w);
-    } else if (rec.x == CS_CL_OR2) {
-      cs_val t[2];
-      for (int k = 0; k < 2; k++) {
-        const int4 l = T.lit[rec.y + k];
-        t[k] = cs_ev_lt_shifted(dom[l.x], dom[l.y], l.z);
-      }
-      v = cs_ev_or(t[0], t[1]);
-    } else if (rec.x == CS_CL_TREE) {
-      cs_tree_scratch S;
-      const int base = T.tree_off[rec.y], len = T.tree_off[rec.y + 1] - base;
-      cs_tree_eval(T, T.tnode + base, len, dom, S.val);
-      v = S.val[len - 1];
-    }
-    vals[c] = v;
+    vals[c] = cs_eval_clause(T, c, dom);
   }
 }
 

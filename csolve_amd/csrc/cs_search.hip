@@ -302,12 +302,15 @@ __global__ __launch_bounds__(SB) void cs_emit(const cs_val *__restrict__ pool, l
                                               const int *__restrict__ block_off, csgpu_node *__restrict__ nodes,
                                               int low_values_last, unsigned scramble) {
   constexpr int PPB = SB / S;
+  __shared__ int s_cnt[PPB];
   const int seg = threadIdx.x / S, sl = threadIdx.x & (S - 1);
-  const int p = blockIdx.x * PPB + seg;
+  const int p0 = blockIdx.x * PPB, p = p0 + seg;
+  if ((int)threadIdx.x < PPB) s_cnt[threadIdx.x] = p0 + (int)threadIdx.x < parents ? child_count[p0 + threadIdx.x] : 0;
+  __syncthreads();
   if (p >= parents) return;
   int beg = block_off[blockIdx.x];
-  for (int j = blockIdx.x * PPB; j < p; j++) beg += child_count[j];
-  cs_emit_seg<S>(pool, first_row + p, n, branch_var[p], beg, child_count[p], nodes, low_values_last, scramble, sl);
+  for (int j = 0; j < seg; j++) beg += s_cnt[j];
+  cs_emit_seg<S>(pool, first_row + p, n, branch_var[p], beg, s_cnt[seg], nodes, low_values_last, scramble, sl);
 }
 
 /* ---- small iterations (at most SMALL_PARENTS parents: always for ANY / MIN / MAX): one workgroup does what
@@ -653,7 +656,8 @@ __global__ __launch_bounds__(SB) void cs_gather_complete(const cs_val *__restric
 __global__ __launch_bounds__(SB) void cs_accept(const cs_val *__restrict__ complete, const int *__restrict__ truth,
                                                 int count, int n, int objective, int obj_var,
                                                 unsigned long long *__restrict__ counters,
-                                                int32_t *__restrict__ solutions, long long max_solutions) {
+                                                int32_t *__restrict__ solutions, long long max_solutions,
+                                                const int *__restrict__ list /* nullable: child i is row list[i] */) {
   const int lane = threadIdx.x & 63;
   int i = blockIdx.x * SB + threadIdx.x;
   if (objective == CS_OBJ_ANY) {
@@ -666,16 +670,17 @@ __global__ __launch_bounds__(SB) void cs_accept(const cs_val *__restrict__ compl
     if (first < 0 || counters[C_STORED] != 0ull) return;
     counters[C_SOLUTIONS] += 1ull;
     counters[C_STORED] = 1ull;
-    for (int v = 0; v < n; v++) solutions[v] = complete[(size_t)first * n + v].lo;
+    for (int v = 0; v < n; v++) solutions[v] = complete[(size_t)(list != nullptr ? list[first] : first) * n + v].lo;
     return;
   }
   const bool ok = i < count && truth[i] == 1;
+  const size_t row = ok ? (size_t)(list != nullptr ? list[i] : i) * n : 0;
   const unsigned long long mask = __ballot(ok);
   if (mask == 0ull) return;
   const int accepted = __popcll(mask), leader = __builtin_ctzll(mask);
   if (objective == CS_OBJ_MIN || objective == CS_OBJ_MAX) {
     int val = objective == CS_OBJ_MIN ? 0x7fffffff : (int)0x80000000;
-    if (ok) val = objective == CS_OBJ_MIN ? complete[(size_t)i * n + obj_var].lo : complete[(size_t)i * n + obj_var].hi;
+    if (ok) val = objective == CS_OBJ_MIN ? complete[row + obj_var].lo : complete[row + obj_var].hi;
     for (int o = 32; o > 0; o >>= 1) {
       const int other = __shfl_xor(val, o);
       val = objective == CS_OBJ_MIN ? (other < val ? other : val) : (other > val ? other : val);
@@ -696,7 +701,7 @@ __global__ __launch_bounds__(SB) void cs_accept(const cs_val *__restrict__ compl
   if (ok) {
     const long long slot = slot0 + __popcll(mask & ((1ull << lane) - 1ull));
     if (slot < max_solutions)
-      for (int v = 0; v < n; v++) solutions[(size_t)slot * n + v] = complete[(size_t)i * n + v].lo;
+      for (int v = 0; v < n; v++) solutions[(size_t)slot * n + v] = complete[row + v].lo;
   }
 }
 
@@ -1133,14 +1138,26 @@ static int one_iteration(csgpu_search *s) {
 
   const int64_t complete = (int64_t)c[C_COMPLETE];
   if (complete > 0) {
-    const unsigned gw = (unsigned)((complete + 3) / 4);
-    hipLaunchKernelGGL(cs_gather_complete, dim3(gw), dim3(SB), 0, 0, s->d_child_states, s->d_complete_list,
-                       (int)complete, n, s->d_complete_states);
-    rc = csgpu_eval_batch(s->m, (const csgpu_val *)s->d_complete_states, s->d_truth, complete, NULL);
-    if (rc != CSGPU_OK) return rc;
-    hipLaunchKernelGGL(cs_accept, dim3((unsigned)((complete + SB - 1) / SB)), dim3(SB), 0, 0, s->d_complete_states,
-                       s->d_truth, (int)complete, n, s->objective, s->obj_var, s->d_counters, s->d_solutions,
-                       (long long)s->max_solutions);
+    if (s->objective == CS_OBJ_ALL) {
+      /* evaluated and accepted where they lie, through the list of their child indices */
+      rc = csgpu_internal_eval_list(s->m, (const csgpu_val *)s->d_child_states, s->d_complete_list,
+                                    (const uint64_t *)(s->d_counters + C_COMPLETE), complete, s->d_truth, NULL);
+      if (rc != CSGPU_OK) return rc;
+      hipLaunchKernelGGL(cs_accept, dim3((unsigned)((complete + SB - 1) / SB)), dim3(SB), 0, 0, s->d_child_states,
+                         s->d_truth, (int)complete, n, s->objective, s->obj_var, s->d_counters, s->d_solutions,
+                         (long long)s->max_solutions, (const int *)s->d_complete_list);
+    } else {
+      /* MIN / MAX keep the complete children of the iteration together: cs_pick_best looks at them one host
+       * round trip later */
+      const unsigned gw = (unsigned)((complete + 3) / 4);
+      hipLaunchKernelGGL(cs_gather_complete, dim3(gw), dim3(SB), 0, 0, s->d_child_states, s->d_complete_list,
+                         (int)complete, n, s->d_complete_states);
+      rc = csgpu_eval_batch(s->m, (const csgpu_val *)s->d_complete_states, s->d_truth, complete, NULL);
+      if (rc != CSGPU_OK) return rc;
+      hipLaunchKernelGGL(cs_accept, dim3((unsigned)((complete + SB - 1) / SB)), dim3(SB), 0, 0, s->d_complete_states,
+                         s->d_truth, (int)complete, n, s->objective, s->obj_var, s->d_counters, s->d_solutions,
+                         (long long)s->max_solutions, (const int *)NULL);
+    }
     /* what accept found is read together with the next iteration's child count (or at the end of the
      * run); ANY stops on the first solution, so it looks at once */
     s->pending_complete = complete;

@@ -387,14 +387,16 @@ static const void *ne_lds_kernel(int width, int n_vars) {
 }
 
 static const void *ne_bitset_kernel(int width, int fw, int n_vars) {
-  /* prefetch depth R = ceil(n_vars/64) when that is 1, 2 or 4 (states of up to 256 variables) */
+  /* prefetch depth R = ceil(n_vars/64) when that is 1, 2 or 4 (states of up to 256 variables), or 10 with
+   * one set word per variable (up to 640 variables: a 25x25 sudoku's next state travels in 40 VGPRs) */
   const int chunks = (n_vars + CS_WAVE - 1) / CS_WAVE;
-  int r = chunks <= 1 ? 1 : (chunks <= 2 ? 2 : (chunks <= 4 ? 4 : 0));
+  int r = chunks <= 1 ? 1 : (chunks <= 2 ? 2 : (chunks <= 4 ? 4 : (chunks <= 10 && fw == 1 ? 10 : 0)));
 #define CS_PICK_R(E, F)                                                                            \
   switch (r) {                                                                                     \
   case 1: return (const void *)cs_propagate_ne_bitset<E, F, 1>;                                    \
   case 2: return (const void *)cs_propagate_ne_bitset<E, F, 2>;                                    \
   case 4: return (const void *)cs_propagate_ne_bitset<E, F, 4>;                                    \
+  case 10: return (const void *)cs_propagate_ne_bitset<E, 1, 10>;                                  \
   default: return (const void *)cs_propagate_ne_bitset<E, F, 0>;                                   \
   }
 #define CS_PICK(E)                                                                                 \
@@ -586,7 +588,7 @@ extern "C" int csgpu_model_finalize(csgpu_model *m) {
       const size_t adj_bytes = (((size_t)m->img->sym_n_adj * (size_t)m->img->sym_width) + 15) & ~(size_t)15;
       const size_t sl = ((size_t)h->n_vars * sizeof(cs_val) + (size_t)h->n_vars * fw * 8 +
                          (2 * (size_t)m->tab.n_words + 2) * sizeof(unsigned) + 15) & ~(size_t)15;
-      for (int waves = 16; waves >= 4; waves >>= 1) {
+      for (int waves = 16; waves >= 1; waves--) { /* as many waves as fit next to the tables */
         const size_t need = off_bytes + base_bytes + adj_bytes + (size_t)waves * sl;
         if (need <= 160u * 1024u) {
           m->fb_words = fw;

@@ -1451,6 +1451,9 @@ __global__ __launch_bounds__(1024, 8) void cs_propagate_ne_packed(
   const int b0 = live ? root_lo[vcl] : 0;
   const int deg = live ? sym_off[vcl + 1] - sym_off[vcl] : 0;
   const unsigned key_base = ((unsigned)v << 26) + (unsigned)bias;
+  /* one segment sum for propagations and revisions when both stay below 2^15: S variables x 64 values, and the
+   * sum of all degrees (uniform) */
+  const bool pack_sums = sym_off[n] < 32768;
   const int row_stride = slots * W * 2;
   const bool have_in = forb_in != nullptr;
   const uint2 *forb_in2 = (const uint2 *)forb_in;
@@ -1493,22 +1496,20 @@ __global__ __launch_bounds__(1024, 8) void cs_propagate_ne_packed(
       pf_n = have_in ? forb_in2[prow] : make_uint2(0u, 0u);
     }
 
-    /* the assignment (step_enter, csolve.c:294-304) and the first variables to push */
+    /* the assignment (step_enter, csolve.c:294-304) and the first variables to push; relative to the root lower
+     * bound (saturating: an assignment may carry the +-infinity sentinels) */
     const bool mine = nvar >= 0 && v == nvar;
-    const int lo_in = b0 + rl, hi_in = b0 + rh;
+    const int from = __builtin_elementwise_sub_sat(nlo, b0), to = __builtin_elementwise_sub_sat(nhi, b0);
+    const bool gone = from > TOP || to < 0 || from > to; /* nothing of the root domain left */
     if (mine) {
-      const long long from = (long long)nlo - b0, to = (long long)nhi - b0;
-      if (from > TOP || to < 0 || from > to) { /* nothing of the root domain left */
-        fb[0] = 0xffffffffu;
-        fb[1] = 0xffffffffu;
-      } else {
-        if (flags & CS_K4_OUT_RESTRICT) cs_set_restrict<2>(fb, (int)from, (int)to);
-        rl = from < 0 ? 0 : (int)from;
-        rh = to > TOP ? TOP : (int)to;
-      }
+      if ((flags & CS_K4_OUT_RESTRICT) && !gone) cs_set_restrict<2>(fb, from, to);
+      fb[0] = gone ? 0xffffffffu : fb[0];
+      fb[1] = gone ? 0xffffffffu : fb[1];
+      rl = gone ? rl : (from < 0 ? 0 : from);
+      rh = gone ? rh : (to > TOP ? TOP : to);
     }
-    /* kernel 4's reference point for the count of propagations: the assigned interval itself */
-    const int lo0 = mine ? nlo : lo_in, hi0 = mine ? nhi : hi_in;
+    /* kernel 4's reference point for the count of propagations: the assigned interval itself (relative) */
+    const int rl0 = mine ? from : rl, rh0 = mine ? to : rh;
     bool pending = live && rl == rh && (!have_in || nvar < 0 || mine);
     unsigned long long failedm = 0ull, pushedm = __ballot(pending);
     unsigned long long rounds_fields = 0ull; /* one S-bit counter per segment */
@@ -1563,8 +1564,19 @@ __global__ __launch_bounds__(1024, 8) void cs_propagate_ne_packed(
 
     const int open_vars = __popc(cs_segment_field<G>(__ballot(rl != rh), g));
     const int lo = b0 + rl, hi = b0 + rh;
-    const int props = cs_segment_sum<S>((lo - lo0) + (hi0 - hi));
-    const int revisions = cs_segment_sum<S>(__builtin_amdgcn_inverse_ballot_w64(pushedm) ? deg : 0);
+    /* propagations (at most 63 per variable, 32 variables) and revisions (at most the sum of all degrees) share
+     * one segment sum, 16 bits each, when the latter fits */
+    const int shaved = (rl - rl0) + (rh0 - rh);
+    const int pushed_deg = __builtin_amdgcn_inverse_ballot_w64(pushedm) ? deg : 0;
+    int props, revisions;
+    if (pack_sums) {
+      const int both = cs_segment_sum<S>((shaved << 16) + pushed_deg);
+      props = both >> 16; /* shaved is non-negative for every input the kernel is specified for */
+      revisions = both & 0xffff;
+    } else {
+      props = cs_segment_sum<S>(shaved);
+      revisions = cs_segment_sum<S>(pushed_deg);
+    }
     const bool failed = __builtin_amdgcn_inverse_ballot_w64(failedm);
     if (flags & CS_K4_OUT_RESTRICT) cs_set_restrict<2>(fb, rl, rh);
     const bool st = valid && live && !failed;

@@ -700,6 +700,10 @@ extern "C" int csgpu_model_qualifies(const csgpu_model *m, int which) {
   }
 }
 
+extern "C" const int32_t *csgpu_internal_root_lo(const csgpu_model *m) {
+  return m != NULL && m->finalized && m->fb_words ? m->d_root_lo : NULL;
+}
+
 extern "C" int csgpu_model_forbidden_words(const csgpu_model *m) { return m && m->finalized ? m->fb_words : 0; }
 
 /* the register-resident forbidden-set kernel (kernel 4); sets_only: the states are the sets alone */

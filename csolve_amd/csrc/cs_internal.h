@@ -29,6 +29,9 @@ int csgpu_internal_propagate_objdev(const csgpu_model *m, const csgpu_val *d_sta
                                     csgpu_val *d_states_out, csgpu_result *d_results, int64_t batch,
                                     const uint64_t *d_batch, int32_t obj_lo, int32_t obj_hi, const int32_t *d_best,
                                     int sense, void *stream);
+/* root lower bounds of the variables in device memory (NULL unless the model qualifies for the forbidden-set
+ * kernels): bit k of a set word = value root_lo + k */
+const int32_t *csgpu_internal_root_lo(const csgpu_model *m);
 /* csgpu_eval_batch over the rows d_list[0 .. *d_count) of d_states, *d_count <= bound */
 int csgpu_internal_eval_list(const csgpu_model *m, const csgpu_val *d_states, const int32_t *d_list,
                              const uint64_t *d_count, int64_t bound, int32_t *d_truth, void *stream);

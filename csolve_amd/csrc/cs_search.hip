@@ -18,10 +18,20 @@
 
 #define SB 256 /* threads per block of the bookkeeping kernels */
 
-/* device counters.  [C_SURVIVORS, C_PER_ITERATION) are zeroed at the start of every iteration; C_SOLUTIONS and
- * C_STORED run over the whole search; C_BEST holds the incumbent (an int in the low half) */
-enum { C_SURVIVORS = 0, C_COMPLETE, C_CUTS, C_PROPS, C_REVS, C_TOTAL_CHILDREN, C_PER_ITERATION,
+/* device counters.  [C_SURVIVORS, C_PER_ITERATION) are zeroed at the start of every iteration (C_SKIPPED: children
+ * cut without a launch, see cs_holes); C_SOLUTIONS and C_STORED run over the whole search; C_BEST holds the
+ * incumbent (an int in the low half) */
+enum { C_SURVIVORS = 0, C_COMPLETE, C_CUTS, C_PROPS, C_REVS, C_TOTAL_CHILDREN, C_SKIPPED, C_PER_ITERATION,
        C_SOLUTIONS = C_PER_ITERATION, C_STORED, C_BEST, C_COUNT };
+
+/* Values that the parent's own forbidden set already rules out (models whose states carry one set word per
+ * variable): the child "variable = such a value" violates a != clause with a valued neighbour, so its fixpoint
+ * can only fail.  Such children are counted as nodes and cuts but never launched: the tree, CALLS and CUTS are
+ * those of enumerating every value of the interval, the batches are a fraction of it. */
+struct cs_holes {
+  const unsigned long long *pool_forb; /* nullptr: every value of the interval becomes a launched child */
+  const int *root_lo;
+};
 
 /* state of the device-driven iterations, in device memory between the kernels of a burst */
 enum { B_TOP = 0, B_BUDGET, B_LIMIT, B_LIMIT_MAX, B_ITER_BASE, B_ITERS, B_NODES, B_CUTS, B_PROPS, B_REVS, B_PEAK, B_ERROR,
@@ -40,7 +50,7 @@ struct csgpu_search {
   int fw;
   unsigned long long *pool_forb, *d_child_forb;
   csgpu_node *d_rebuild_nodes;
-  int *d_branch_var, *d_child_count, *d_child_off /* per workgroup of cs_branch */, *d_block_sum;
+  int *d_branch_var, *d_child_count, *d_child_off /* per workgroup of cs_branch */, *d_block_sum, *d_block_skip;
   csgpu_node *d_nodes;
   cs_val *d_child_states, *d_complete_states;
   csgpu_result *d_results;
@@ -63,6 +73,7 @@ struct csgpu_search {
   hipStream_t burst_stream;
   hipGraphExec_t burst_exec;
   int64_t burst_limit; /* parents per iteration the graph was built for (0: none) */
+  cs_holes holes;      /* values a parent's own set forbids are cut without a launch (one set word per variable) */
   int burst_off;       /* CSGPU_SEARCH_BURST=0: every iteration driven from the host */
   int graph_off;       /* CSGPU_SEARCH_GRAPH=0: the launches of a burst enqueued one by one */
 };
@@ -77,6 +88,34 @@ static int flush_accept_results(csgpu_search *s);
     hipError_t e_ = (expr);                                                    \
     if (e_ != hipSuccess) return fail(CSGPU_E_HIP, hipGetErrorString(e_));     \
   } while (0)
+
+/* the values lo .. lo + width - 1 of a variable whose set word is `forb` (bit k = value root_lo + k):
+ * bit j of the result <=> value lo + j is not forbidden.  32-bit halves (no variable 64-bit shifts). */
+__device__ __forceinline__ void cs_allowed_values(unsigned long long forb, int rel_lo, int width, unsigned *a_lo,
+                                                  unsigned *a_hi) {
+  const unsigned lo = ~(unsigned)forb, hi = ~(unsigned)(forb >> 32);
+  unsigned x_lo, x_hi;
+  if (rel_lo >= 32) { x_lo = hi >> (rel_lo - 32); x_hi = 0u; }
+  else if (rel_lo == 0) { x_lo = lo; x_hi = hi; }
+  else { x_lo = (lo >> rel_lo) | (hi << (32 - rel_lo)); x_hi = hi >> rel_lo; }
+  if (width < 32) { x_lo &= (1u << width) - 1u; x_hi = 0u; }
+  else if (width == 32) x_hi = 0u;
+  else if (width < 64) x_hi &= (1u << (width - 32)) - 1u;
+  *a_lo = x_lo;
+  *a_hi = x_hi;
+}
+
+/* -> 1 and the mask of allowed values if the holes of variable `var` of this row may be skipped */
+__device__ __forceinline__ int cs_row_holes(const cs_holes &H, const cs_val *__restrict__ row, long long row_index, int n,
+                                            int var, unsigned *a_lo, unsigned *a_hi) {
+  if (H.pool_forb == nullptr || var < 0) return 0;
+  const cs_val d = row[var];
+  const long long width = (long long)d.hi - (long long)d.lo + 1;
+  const long long rel_lo = (long long)d.lo - (long long)H.root_lo[var];
+  if (width > 64 || rel_lo < 0 || rel_lo + width > 64) return 0;
+  cs_allowed_values(H.pool_forb[(size_t)row_index * n + var], (int)rel_lo, (int)width, a_lo, a_hi);
+  return 1;
+}
 
 /* S lanes (a whole wave, or a half or a quarter of one for small models) per parent: the open variable with
  * the smallest interval (ties: lowest index), the reference's "-o smallest-domain" idea (strategy.c:85-91) as a
@@ -113,25 +152,35 @@ __device__ __forceinline__ void cs_branch_seg(const cs_val *__restrict__ row, in
 template <int S>
 __global__ __launch_bounds__(SB) void cs_branch(const cs_val *__restrict__ pool, long long first_row, int parents,
                                                 int n, int *__restrict__ branch_var, int *__restrict__ child_count,
-                                                int *__restrict__ block_sum) {
+                                                int *__restrict__ block_sum, cs_holes H,
+                                                int *__restrict__ block_skip) {
   constexpr int PPB = SB / S;
-  __shared__ int s_cnt[PPB];
+  __shared__ int s_cnt[PPB], s_skip[PPB];
   const int seg = threadIdx.x / S, sl = threadIdx.x & (S - 1);
   const int p = blockIdx.x * PPB + seg;
   const int pc = p < parents ? p : parents - 1; /* segments past the end redo the last parent and drop it */
-  int var, count;
-  cs_branch_seg<S>(pool + (size_t)(first_row + pc) * n, n, sl, &var, &count);
+  int var, count, skipped = 0;
+  const cs_val *row = pool + (size_t)(first_row + pc) * n;
+  cs_branch_seg<S>(row, n, sl, &var, &count);
+  unsigned a_lo, a_hi;
+  if (cs_row_holes(H, row, first_row + pc, n, var, &a_lo, &a_hi)) {
+    const int allowed = __popc(a_lo) + __popc(a_hi);
+    skipped = count - allowed;
+    count = allowed;
+  }
   if (sl == 0) {
     if (p < parents) {
       branch_var[p] = var;
       child_count[p] = count;
     }
     s_cnt[seg] = p < parents ? count : 0;
+    s_skip[seg] = p < parents ? skipped : 0;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    int total = 0;
-    for (int i = 0; i < PPB; i++) total += s_cnt[i];
+    int total = 0, skip = 0;
+    for (int i = 0; i < PPB; i++) { total += s_cnt[i]; skip += s_skip[i]; }
+    block_skip[blockIdx.x] = skip; /* summed by cs_scan */
     block_sum[blockIdx.x] = total;
   }
 }
@@ -163,9 +212,11 @@ __device__ __forceinline__ long long cs_block_excl_scan(long long x, long long *
  * counters[total_slot].  count and off are 16-byte aligned (hipMalloc), the tail is handled one by one. */
 #define SCAN_PER 16
 __global__ __launch_bounds__(1024) void cs_scan(const int *__restrict__ count, int items, int *__restrict__ off,
-                                                unsigned long long *__restrict__ counters, int total_slot) {
+                                                unsigned long long *__restrict__ counters, int total_slot,
+                                                const int *__restrict__ extra /* nullable: summed into extra_slot */,
+                                                int extra_slot) {
   __shared__ long long s_part[16];
-  long long carry = 0;
+  long long carry = 0, extra_sum = 0;
   for (int base = 0; base < items; base += 1024 * SCAN_PER) {
     const int first = base + (int)threadIdx.x * SCAN_PER;
     int x[SCAN_PER];
@@ -179,6 +230,8 @@ __global__ __launch_bounds__(1024) void cs_scan(const int *__restrict__ count, i
 #pragma unroll
       for (int q = 0; q < SCAN_PER; q++) x[q] = first + q < items ? count[first + q] : 0;
     }
+    if (extra != nullptr)
+      for (int q = 0; q < SCAN_PER; q++) extra_sum += first + q < items ? extra[first + q] : 0;
     int sum = 0;
 #pragma unroll
     for (int q = 0; q < SCAN_PER; q++) { const int v = x[q]; x[q] = sum; sum += v; } /* exclusive within the thread */
@@ -195,9 +248,12 @@ __global__ __launch_bounds__(1024) void cs_scan(const int *__restrict__ count, i
     }
     carry += total;
   }
+  long long extra_total = 0;
+  if (extra != nullptr) (void)cs_block_excl_scan(extra_sum, s_part, &extra_total);
   if (threadIdx.x == 0) {
     off[items] = (int)carry;
     counters[total_slot] = (unsigned long long)carry;
+    if (extra != nullptr) counters[extra_slot] = (unsigned long long)extra_total;
   }
 }
 
@@ -257,10 +313,34 @@ __global__ __launch_bounds__(1024) void cs_scan_classes(const int *__restrict__ 
 template <int S>
 __device__ __forceinline__ void cs_emit_seg(const cs_val *__restrict__ pool, long long row, int n, int var, int beg, int cnt,
                                             csgpu_node *__restrict__ nodes, int low_values_last, unsigned scramble,
-                                            int sl) {
+                                            int sl, const cs_holes &H) {
   if (var < 0) return;
   const cs_val d = pool[(size_t)row * n + var];
   const long long width = (long long)d.hi - (long long)d.lo + 1;
+  unsigned a_lo, a_hi;
+  if (cs_row_holes(H, pool + (size_t)row * n, row, n, var, &a_lo, &a_hi)) {
+    /* only the values the parent's set allows (cnt of them, as cs_branch counted): value lo + j is the r-th
+     * allowed one from below and takes the place the r-th value has in the full enumeration below */
+    unsigned h = 0u;
+    if (scramble != 0u && cnt > 0) {
+      h = (scramble ^ (unsigned)var * 2654435761u ^ (unsigned)row * 40503u);
+      h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+      h %= (unsigned)cnt;
+    }
+    for (int j = sl; j < (int)width; j += S) {
+      const unsigned bit = j < 32 ? (a_lo >> j) & 1u : (a_hi >> (j - 32)) & 1u;
+      if (bit == 0u) continue;
+      const int r = j < 32 ? __popc(a_lo & ((1u << j) - 1u)) : __popc(a_lo) + __popc(a_hi & ((1u << (j - 32)) - 1u));
+      const int k = scramble != 0u ? (int)(((unsigned)r + (unsigned)cnt - h) % (unsigned)cnt) : (low_values_last ? cnt - 1 - r : r);
+      csgpu_node nd;
+      nd.var = var;
+      nd.lo = d.lo + j;
+      nd.hi = d.lo + j;
+      nd.parent = (int)row;
+      nodes[beg + k] = nd;
+    }
+    return;
+  }
   if (width > SPLIT_WIDTH) { /* two halves, lower half first */
     const int mid = (int)(((long long)d.lo + (long long)d.hi) >> 1);
     if (sl < 2) {
@@ -300,7 +380,7 @@ template <int S>
 __global__ __launch_bounds__(SB) void cs_emit(const cs_val *__restrict__ pool, long long first_row, int parents, int n,
                                               const int *__restrict__ branch_var, const int *__restrict__ child_count,
                                               const int *__restrict__ block_off, csgpu_node *__restrict__ nodes,
-                                              int low_values_last, unsigned scramble) {
+                                              int low_values_last, unsigned scramble, cs_holes H) {
   constexpr int PPB = SB / S;
   __shared__ int s_cnt[PPB];
   const int seg = threadIdx.x / S, sl = threadIdx.x & (S - 1);
@@ -310,7 +390,7 @@ __global__ __launch_bounds__(SB) void cs_emit(const cs_val *__restrict__ pool, l
   if (p >= parents) return;
   int beg = block_off[blockIdx.x];
   for (int j = 0; j < seg; j++) beg += s_cnt[j];
-  cs_emit_seg<S>(pool, first_row + p, n, branch_var[p], beg, s_cnt[seg], nodes, low_values_last, scramble, sl);
+  cs_emit_seg<S>(pool, first_row + p, n, branch_var[p], beg, s_cnt[seg], nodes, low_values_last, scramble, sl, H);
 }
 
 /* ---- small iterations (at most SMALL_PARENTS parents: always for ANY / MIN / MAX): one workgroup does what
@@ -320,25 +400,36 @@ __global__ __launch_bounds__(SB) void cs_emit(const cs_val *__restrict__ pool, l
 __global__ __launch_bounds__(1024) void cs_expand_small(const cs_val *__restrict__ pool, long long first_row, int parents,
                                                         int n, csgpu_node *__restrict__ nodes,
                                                         unsigned long long *__restrict__ counters, int low_values_last,
-                                                        unsigned scramble) {
-  __shared__ int s_var[SMALL_PARENTS], s_cnt[SMALL_PARENTS], s_off[SMALL_PARENTS];
+                                                        unsigned scramble, cs_holes H) {
+  __shared__ int s_var[SMALL_PARENTS], s_cnt[SMALL_PARENTS], s_off[SMALL_PARENTS], s_skip[SMALL_PARENTS];
   __shared__ long long s_part[16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x < C_PER_ITERATION) counters[threadIdx.x] = 0ull;
   for (int p = wave; p < parents; p += 16) {
-    int var, count;
-    cs_branch_seg<64>(pool + (size_t)(first_row + p) * n, n, lane, &var, &count);
-    if (lane == 0) { s_var[p] = var; s_cnt[p] = count; }
+    int var, count, skipped = 0;
+    const cs_val *row = pool + (size_t)(first_row + p) * n;
+    cs_branch_seg<64>(row, n, lane, &var, &count);
+    unsigned a_lo, a_hi;
+    if (cs_row_holes(H, row, first_row + p, n, var, &a_lo, &a_hi)) {
+      const int allowed = __popc(a_lo) + __popc(a_hi);
+      skipped = count - allowed;
+      count = allowed;
+    }
+    if (lane == 0) { s_var[p] = var; s_cnt[p] = count; s_skip[p] = skipped; }
   }
   __syncthreads();
-  long long total;
+  long long total, skipped_total;
   const int t = (int)threadIdx.x;
+  (void)cs_block_excl_scan(t < parents ? (long long)s_skip[t] : 0, s_part, &skipped_total);
   const long long ex = cs_block_excl_scan(t < parents ? (long long)s_cnt[t] : 0, s_part, &total);
   if (t < parents) s_off[t] = (int)ex;
-  if (t == 0) counters[C_TOTAL_CHILDREN] = (unsigned long long)total;
+  if (t == 0) {
+    counters[C_TOTAL_CHILDREN] = (unsigned long long)total;
+    counters[C_SKIPPED] = (unsigned long long)skipped_total;
+  }
   __syncthreads();
   for (int p = wave; p < parents; p += 16)
-    cs_emit_seg<64>(pool, first_row + p, n, s_var[p], s_off[p], s_cnt[p], nodes, low_values_last, scramble, lane);
+    cs_emit_seg<64>(pool, first_row + p, n, s_var[p], s_off[p], s_cnt[p], nodes, low_values_last, scramble, lane, H);
 }
 
 
@@ -458,8 +549,9 @@ __global__ __launch_bounds__(1024) void cs_classify_small(const csgpu_result *__
 __global__ __launch_bounds__(1024) void cs_expand_burst(const cs_val *__restrict__ pool, int n, csgpu_node *__restrict__ nodes,
                                                         unsigned long long *__restrict__ counters,
                                                         unsigned long long *__restrict__ burst, int objective,
-                                                        long long max_width, long long cap, long long room_limit) {
-  __shared__ int s_var[SMALL_PARENTS], s_cnt[SMALL_PARENTS], s_off[SMALL_PARENTS];
+                                                        long long max_width, long long cap, long long room_limit,
+                                                        cs_holes H) {
+  __shared__ int s_var[SMALL_PARENTS], s_cnt[SMALL_PARENTS], s_off[SMALL_PARENTS], s_skip[SMALL_PARENTS];
   __shared__ long long s_part[16];
   __shared__ long long s_first, s_iter;
   __shared__ int s_parents;
@@ -496,25 +588,35 @@ __global__ __launch_bounds__(1024) void cs_expand_burst(const cs_val *__restrict
   const unsigned scramble =
       objective == CS_OBJ_ANY ? (unsigned)((unsigned long long)s_iter * 2654435761ull + 0x9e3779b9u) | 1u : 0u;
   for (int p = wave; p < parents; p += 16) {
-    int var, count;
-    cs_branch_seg<64>(pool + (size_t)(first_row + p) * n, n, lane, &var, &count);
-    if (lane == 0) { s_var[p] = var; s_cnt[p] = count; }
+    int var, count, skipped = 0;
+    const cs_val *row = pool + (size_t)(first_row + p) * n;
+    cs_branch_seg<64>(row, n, lane, &var, &count);
+    unsigned a_lo, a_hi;
+    if (cs_row_holes(H, row, first_row + p, n, var, &a_lo, &a_hi)) {
+      const int allowed = __popc(a_lo) + __popc(a_hi);
+      skipped = count - allowed;
+      count = allowed;
+    }
+    if (lane == 0) { s_var[p] = var; s_cnt[p] = count; s_skip[p] = skipped; }
   }
   __syncthreads();
-  long long total;
+  long long total, skipped_total;
   const int t = (int)threadIdx.x;
+  (void)cs_block_excl_scan(t < parents ? (long long)s_skip[t] : 0, s_part, &skipped_total);
   const long long ex = cs_block_excl_scan(t < parents ? (long long)s_cnt[t] : 0, s_part, &total);
   if (t < parents) s_off[t] = (int)ex;
   if (t == 0) {
     counters[C_TOTAL_CHILDREN] = (unsigned long long)total;
+    counters[C_SKIPPED] = (unsigned long long)skipped_total;
     burst[B_TOP] = (unsigned long long)first_row;
     burst[B_ITERS] += 1ull;
     burst[B_BUDGET] -= 1ull;
-    burst[B_NODES] += (unsigned long long)total;
+    burst[B_NODES] += (unsigned long long)(total + skipped_total);
+    burst[B_CUTS] += (unsigned long long)skipped_total;
   }
   __syncthreads();
   for (int p = wave; p < parents; p += 16)
-    cs_emit_seg<64>(pool, first_row + p, n, s_var[p], s_off[p], s_cnt[p], nodes, low_values_last, scramble, lane);
+    cs_emit_seg<64>(pool, first_row + p, n, s_var[p], s_off[p], s_cnt[p], nodes, low_values_last, scramble, lane, H);
 }
 
 /* cs_accept + cs_pick_best for the complete children of a small iteration, one workgroup, nothing read by the
@@ -732,7 +834,7 @@ __global__ __launch_bounds__(SB) void cs_move_rows(unsigned long long *__restric
 extern "C" void csgpu_search_free(csgpu_search *s) {
   if (s == NULL) return;
   (void)hipFree(s->pool_forb); (void)hipFree(s->d_child_forb); (void)hipFree(s->d_rebuild_nodes);
-  (void)hipFree(s->pool); (void)hipFree(s->d_branch_var); (void)hipFree(s->d_child_count); (void)hipFree(s->d_child_off); (void)hipFree(s->d_block_sum);
+  (void)hipFree(s->pool); (void)hipFree(s->d_branch_var); (void)hipFree(s->d_child_count); (void)hipFree(s->d_child_off); (void)hipFree(s->d_block_sum); (void)hipFree(s->d_block_skip);
   (void)hipFree(s->d_nodes); (void)hipFree(s->d_child_states); (void)hipFree(s->d_complete_states);
   (void)hipFree(s->d_results); (void)hipFree(s->d_dest); (void)hipFree(s->d_complete_list); (void)hipFree(s->d_truth);
   (void)hipFree(s->d_block_surv); (void)hipFree(s->d_block_comp); (void)hipFree(s->d_surv_off); (void)hipFree(s->d_comp_off);
@@ -812,6 +914,7 @@ extern "C" int csgpu_search_create(const csgpu_model *m, int64_t pool_capacity, 
   ALLOC(s->d_child_count, sizeof(int) * (size_t)max_children);
   ALLOC(s->d_child_off, sizeof(int) * ((size_t)max_children + 1));
   ALLOC(s->d_block_sum, sizeof(int) * ((size_t)max_children + 1));
+  ALLOC(s->d_block_skip, sizeof(int) * ((size_t)max_children + 1));
   ALLOC(s->d_nodes, sizeof(csgpu_node) * (size_t)max_children);
   ALLOC(s->d_child_states, row * (size_t)max_children);
   ALLOC(s->d_complete_states, row * (size_t)max_children);
@@ -836,6 +939,12 @@ extern "C" int csgpu_search_create(const csgpu_model *m, int64_t pool_capacity, 
 #undef ALLOC
   HIP_OK(hipMemset(s->d_counters, 0, sizeof(unsigned long long) * C_COUNT));
   HIP_OK(hipMemcpy(s->d_best, &s->st.best, sizeof(int), hipMemcpyHostToDevice));
+  s->holes.pool_forb = NULL;
+  s->holes.root_lo = csgpu_internal_root_lo(m);
+  {
+    const char *e = getenv("CSGPU_SEARCH_HOLES");
+    if (s->fw == 1 && s->holes.root_lo != NULL && !(e != NULL && e[0] == '0')) s->holes.pool_forb = s->pool_forb;
+  }
   HIP_OK(hipMalloc((void **)&s->d_burst, sizeof(unsigned long long) * B_COUNT));
   HIP_OK(hipHostMalloc((void **)&s->h_burst, sizeof(unsigned long long) * (B_COUNT + C_COUNT), 0));
   HIP_OK(hipStreamCreate(&s->burst_stream));
@@ -1029,37 +1138,39 @@ static int one_iteration(csgpu_search *s) {
   int32_t obj_lo = CS_DOM_MIN, obj_hi = CS_DOM_MAX;
   if (s->objective == CS_OBJ_MIN) obj_hi = cs_add(s->st.best, cs_neg(1));
   if (s->objective == CS_OBJ_MAX) obj_lo = cs_add(s->st.best, 1);
+  unsigned long long skipped_now = 0; /* large path: children cut without a launch, known with the child count */
   int64_t children;          /* what the launches are sized for */
   const uint64_t *d_children; /* where the real count is, when the host does not know it yet */
   if (small) {
     /* one workgroup expands; nothing is read back before the fixpoint is launched */
     hipLaunchKernelGGL(cs_expand_small, dim3(1), dim3(1024), 0, 0, s->pool, first_row, (int)parents, n, s->d_nodes,
-                       s->d_counters, low_last, scramble);
+                       s->d_counters, low_last, scramble, s->holes);
     children = parents * s->max_width;
     d_children = (const uint64_t *)(s->d_counters + C_TOTAL_CHILDREN);
   } else {
-    HIP_OK(hipMemsetAsync(s->d_counters, 0, sizeof(unsigned long long) * C_PER_ITERATION, 0));
     unsigned pb;
     for (;;) {
+      HIP_OK(hipMemsetAsync(s->d_counters, 0, sizeof(unsigned long long) * C_PER_ITERATION, 0));
       /* 16, 32 or 64 lanes per parent */
       const int ppb = n <= 16 ? SB / 16 : (n <= 32 ? SB / 32 : SB / 64);
       pb = (unsigned)((parents + ppb - 1) / ppb);
       if (n <= 16)
         hipLaunchKernelGGL(cs_branch<16>, dim3(pb), dim3(SB), 0, 0, s->pool, first_row, (int)parents, n, s->d_branch_var,
-                           s->d_child_count, s->d_block_sum);
+                           s->d_child_count, s->d_block_sum, s->holes, s->d_block_skip);
       else if (n <= 32)
         hipLaunchKernelGGL(cs_branch<32>, dim3(pb), dim3(SB), 0, 0, s->pool, first_row, (int)parents, n, s->d_branch_var,
-                           s->d_child_count, s->d_block_sum);
+                           s->d_child_count, s->d_block_sum, s->holes, s->d_block_skip);
       else
         hipLaunchKernelGGL(cs_branch<64>, dim3(pb), dim3(SB), 0, 0, s->pool, first_row, (int)parents, n, s->d_branch_var,
-                           s->d_child_count, s->d_block_sum);
+                           s->d_child_count, s->d_block_sum, s->holes, s->d_block_skip);
       hipLaunchKernelGGL(cs_scan, dim3(1), dim3(1024), 0, 0, s->d_block_sum, (int)pb, s->d_child_off, s->d_counters,
-                         (int)C_TOTAL_CHILDREN);
+                         (int)C_TOTAL_CHILDREN, (const int *)s->d_block_skip, (int)C_SKIPPED);
       /* first host read of the iteration: the number of children, and with it what the previous
        * iteration's accept left behind (solutions so far, incumbent) */
       unsigned long long head[C_COUNT - C_TOTAL_CHILDREN];
       HIP_OK(hipMemcpy(head, s->d_counters + C_TOTAL_CHILDREN, sizeof head, hipMemcpyDeviceToHost));
       children = (int64_t)head[0];
+      skipped_now = head[C_SKIPPED - C_TOTAL_CHILDREN];
       int rc0 = apply_accept_results(s, head[C_SOLUTIONS - C_TOTAL_CHILDREN], (int)(unsigned)head[C_BEST - C_TOTAL_CHILDREN]);
       if (rc0 != CSGPU_OK) return rc0;
       if (adaptive) s->avg_children = 0.5 * s->avg_children + 0.5 * ((double)children / (double)parents);
@@ -1075,20 +1186,24 @@ static int one_iteration(csgpu_search *s) {
     if (children > s->max_children) return fail(CSGPU_E_LIMIT, "internal: more children than the batch buffers hold");
     if (n <= 16)
       hipLaunchKernelGGL(cs_emit<16>, dim3(pb), dim3(SB), 0, 0, s->pool, first_row, (int)parents, n, s->d_branch_var,
-                         s->d_child_count, s->d_child_off, s->d_nodes, low_last, scramble);
+                         s->d_child_count, s->d_child_off, s->d_nodes, low_last, scramble, s->holes);
     else if (n <= 32)
       hipLaunchKernelGGL(cs_emit<32>, dim3(pb), dim3(SB), 0, 0, s->pool, first_row, (int)parents, n, s->d_branch_var,
-                         s->d_child_count, s->d_child_off, s->d_nodes, low_last, scramble);
+                         s->d_child_count, s->d_child_off, s->d_nodes, low_last, scramble, s->holes);
     else
       hipLaunchKernelGGL(cs_emit<64>, dim3(pb), dim3(SB), 0, 0, s->pool, first_row, (int)parents, n, s->d_branch_var,
-                         s->d_child_count, s->d_child_off, s->d_nodes, low_last, scramble);
+                         s->d_child_count, s->d_child_off, s->d_nodes, low_last, scramble, s->holes);
     /* the incumbent may just have improved */
     if (s->objective == CS_OBJ_MIN) obj_hi = cs_add(s->st.best, cs_neg(1));
     if (s->objective == CS_OBJ_MAX) obj_lo = cs_add(s->st.best, 1);
   }
   s->top -= parents;
   s->st.iterations++;
-  if (children == 0) return CSGPU_OK;
+  if (children == 0) { /* (large path only) every child was cut by its parent's own set */
+    s->st.nodes += skipped_now;
+    s->st.cuts += skipped_now;
+    return CSGPU_OK;
+  }
 
   int rc;
   if (s->fw > 0)
@@ -1131,8 +1246,8 @@ static int one_iteration(csgpu_search *s) {
   }
   s->top += (int64_t)c[C_SURVIVORS];
   if (s->top > s->peak) s->peak = s->top;
-  s->st.nodes += (uint64_t)children;
-  s->st.cuts += c[C_CUTS];
+  s->st.nodes += (uint64_t)children + c[C_SKIPPED];
+  s->st.cuts += c[C_CUTS] + c[C_SKIPPED];
   s->st.props += c[C_PROPS];
   s->st.revisions += c[C_REVS];
 
@@ -1193,7 +1308,7 @@ static int enqueue_burst(csgpu_search *s, hipStream_t st) {
   while (cpb > 4 && bound / cpb < 2048) cpb >>= 1;
   for (int it = 0; it < BURST_ITERATIONS; it++) {
     hipLaunchKernelGGL(cs_expand_burst, dim3(1), dim3(1024), 0, st, s->pool, n, s->d_nodes, s->d_counters, s->d_burst,
-                       s->objective, (long long)s->max_width, (long long)s->cap, room_limit);
+                       s->objective, (long long)s->max_width, (long long)s->cap, room_limit, s->holes);
     int rc;
     if (s->fw > 0)
       rc = csgpu_internal_propagate_fb(s->m, (const csgpu_val *)s->pool, (const uint64_t *)s->pool_forb, s->d_nodes,

@@ -231,3 +231,28 @@ def test_device_driven_iterations_equal_host_driven_ones(name, best, monkeypatch
     assert stats["graph"] == stats["launches"]  # the graph is only a way of launching
     # the host-driven loop learns of a new incumbent one iteration later, so it may expand a few more nodes
     assert stats["host"]["nodes"] >= stats["graph"]["nodes"]
+
+
+def test_children_cut_by_their_parents_set_are_counted_not_launched(monkeypatch):
+    """Values that a parent's own forbidden set rules out are cut without a fixpoint launch
+    (CSGPU_SEARCH_HOLES=0 launches every value of the interval): the same tree either way --
+    nodes, cuts, solutions -- for ALL, and the same first solution for ANY."""
+    from csolve_amd import problems
+    from csolve_amd.solver import Search, solve_root
+    for text, keys in ((problems.queens(11, "ALL"), ("nodes", "cuts", "solutions")),
+                       (problems.offsets(14, 24, 3, "ALL"), ("nodes", "cuts", "solutions")),
+                       (problems.queens(40, "ANY"), ("solutions",))):
+        model = solve_root(text)
+        runs, sols = [], []
+        for holes in ("1", "0"):
+            monkeypatch.setenv("CSGPU_SEARCH_HOLES", holes)
+            s = Search(model, 1 << 18, 1 << 14)
+            s.put(model.root_state())
+            st = s.run()
+            assert st["done"] == 1
+            runs.append({k: st[k] for k in keys})
+            sols.append(s.solutions(1)[0] if st["solutions"] else None)
+        assert runs[0] == runs[1]
+        assert runs[0]["solutions"] >= 1
+        if "nodes" not in keys:
+            assert (sols[0] == sols[1]).all()

@@ -236,23 +236,21 @@ def test_device_driven_iterations_equal_host_driven_ones(name, best, monkeypatch
 def test_children_cut_by_their_parents_set_are_counted_not_launched(monkeypatch):
     """Values that a parent's own forbidden set rules out are cut without a fixpoint launch
     (CSGPU_SEARCH_HOLES=0 launches every value of the interval): the same tree either way --
-    nodes, cuts, solutions -- for ALL, and the same first solution for ANY."""
+    nodes, cuts, solutions -- for ALL; ANY reaches a valid solution either way (its value order is a
+    rotation of the launched children, so the first solution may differ)."""
     from csolve_amd import problems
     from csolve_amd.solver import Search, solve_root
-    for text, keys in ((problems.queens(11, "ALL"), ("nodes", "cuts", "solutions")),
-                       (problems.offsets(14, 24, 3, "ALL"), ("nodes", "cuts", "solutions")),
-                       (problems.queens(40, "ANY"), ("solutions",))):
-        model = solve_root(text)
-        runs, sols = [], []
+    for n, objective in ((9, "ALL"), (11, "ALL"), (40, "ANY")):
+        model = solve_root(problems.queens(n, objective))
+        runs = []
         for holes in ("1", "0"):
             monkeypatch.setenv("CSGPU_SEARCH_HOLES", holes)
             s = Search(model, 1 << 18, 1 << 14)
             s.put(model.root_state())
-            st = s.run()
-            assert st["done"] == 1
-            runs.append({k: st[k] for k in keys})
-            sols.append(s.solutions(1)[0] if st["solutions"] else None)
-        assert runs[0] == runs[1]
-        assert runs[0]["solutions"] >= 1
-        if "nodes" not in keys:
-            assert (sols[0] == sols[1]).all()
+            st = s.run(20000)
+            assert st["done"] == 1 and st["solutions"] >= 1
+            runs.append({k: st[k] for k in ("nodes", "cuts", "solutions")})
+            row = s.solutions(1)[0]
+            assert len(set(row)) == n and len(set(row + np.arange(n))) == n and len(set(row - np.arange(n))) == n
+        if objective == "ALL":
+            assert runs[0] == runs[1]

@@ -230,8 +230,17 @@ __global__ __launch_bounds__(1024) void cs_scan(const int *__restrict__ count, i
 #pragma unroll
       for (int q = 0; q < SCAN_PER; q++) x[q] = first + q < items ? count[first + q] : 0;
     }
-    if (extra != nullptr)
-      for (int q = 0; q < SCAN_PER; q++) extra_sum += first + q < items ? extra[first + q] : 0;
+    if (extra != nullptr) {
+      if (first + SCAN_PER <= items) {
+#pragma unroll
+        for (int q = 0; q < SCAN_PER / 4; q++) {
+          const int4 v = ((const int4 *)(extra + first))[q];
+          extra_sum += (long long)v.x + v.y + v.z + v.w;
+        }
+      } else {
+        for (int q = 0; q < SCAN_PER; q++) extra_sum += first + q < items ? extra[first + q] : 0;
+      }
+    }
     int sum = 0;
 #pragma unroll
     for (int q = 0; q < SCAN_PER; q++) { const int v = x[q]; x[q] = sum; sum += v; } /* exclusive within the thread */

@@ -206,11 +206,15 @@ int csgpu_eval_clauses(const csgpu_model *m, const csgpu_val *d_state, csgpu_val
  * The search tree is the reference's (same children, same propagation per child); the ORDER in
  * which it is walked is not, so CALLS/CUTS are engine-specific while the set of solutions and
  * the optimum are not.  Subtree sharding across GPUs moves whole states between the pools of
- * different ranks (csgpu_search_take / _put) and exchanges the incumbent (_set_best). */
+ * different ranks (csgpu_search_take / _put) and exchanges the incumbent (_set_best).
+ * When the states carry one forbidden-set word per variable, a child whose value the parent's own
+ * set already forbids (a valued neighbour rules it out, so its propagation can only fail) is counted
+ * in `nodes` and `cuts` without being launched; CSGPU_SEARCH_HOLES=0 launches those too (same
+ * counts, same solutions). */
 typedef struct csgpu_search csgpu_search;
 
 typedef struct csgpu_search_stats {
-  uint64_t nodes;      /* children propagated = CALLS */
+  uint64_t nodes;      /* children = CALLS */
   uint64_t cuts;       /* inconsistent children = CUTS */
   uint64_t props;      /* narrowing events = PROPS */
   uint64_t revisions;  /* clause revisions */

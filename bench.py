@@ -244,7 +244,8 @@ def search_workload(args, rank, world, local, dist):
     def once():
         eng.reset()
         sh = ShardedSearch(eng, model.objective, n, rank, world, dist, engine_device="cuda", comm_device=comm,
-                           slice_iterations=args.slice, seed_states_per_rank=256, low_water=4096)
+                           slice_iterations=args.slice or (8 if model.objective == 1 else 32),  # 1 = ALL (csolve_amd/parallel.py)
+                           seed_states_per_rank=256, low_water=4096)
         local_stats, totals = sh.run(model.root_state(), args.search_slices if args.search_slices > 0 else 1 << 40)
         return local_stats, totals, sh
 
@@ -290,8 +291,9 @@ def search_workload(args, rank, world, local, dist):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 200; 3 for --workload search, where a "
+                    "step is one complete search)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps before (default 10; 1 for --workload search)")
     ap.add_argument("--queens", type=int, default=64)
     ap.add_argument("--schedule", type=int, default=0, help="tasks of a schedule.txt-style optimisation model (tree clauses, "
                     "general kernel) instead of queens (BASELINE configs[4] shape)")
@@ -308,19 +310,25 @@ def main():
                     help="intervals: {lo,hi} states with the forbidden sets next to them (default); sets: the states are "
                          "the forbidden sets alone (csgpu_propagate_batch_sets, kernel 4 models), half the bytes per node")
     ap.add_argument("--workload", choices=["propagate", "search"], default="propagate")
-    ap.add_argument("--search-queens", type=int, default=13)
+    ap.add_argument("--search-queens", type=int, default=17, help="queens-N tree of the search workload (ALL: 17 is "
+                    "95,815,104 solutions, 6.2e9 nodes, about a second on one GPU)")
     ap.add_argument("--search-objective", choices=["ALL", "ANY"], default="ALL")
     ap.add_argument("--search-schedule", type=int, default=0, help="search workload on a schedule.txt-style MIN model of this "
                     "many tasks instead of queens (BASELINE configs[4] shape: the incumbent bound travels between the ranks)")
     ap.add_argument("--pool", type=int, default=0, help="search workload: rows of the state pool (default: 8 x --children)")
     ap.add_argument("--children", type=int, default=0, help="search workload: children per iteration at most "
                     "(default: 2^21 for models of at most 32 variables, else 2^19)")
-    ap.add_argument("--slice", type=int, default=32, help="search iterations between rank exchanges")
+    ap.add_argument("--slice", type=int, default=0, help="search iterations between rank exchanges (default: 8 for ALL, "
+                    "whose iterations are large batches; 32 for ANY / MIN / MAX = two device-driven bursts)")
     ap.add_argument("--search-slices", type=int, default=0,
                     help="stop a search after this many slices (0 = run to the end): ALL on trees too large to finish")
     ap.add_argument("--comm", choices=["nccl", "gloo"], default="nccl")
     ap.add_argument("--same-device", action="store_true", help="all ranks on cuda:0 (rehearsal on a 1-GPU box, use --comm gloo)")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 3 if args.workload == "search" else 200
+    if args.warmup is None:
+        args.warmup = 1 if args.workload == "search" else 10
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

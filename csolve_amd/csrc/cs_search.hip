@@ -511,21 +511,31 @@ __global__ __launch_bounds__(1024) void cs_classify_small(const csgpu_result *__
   const int children = (int)counters[C_TOTAL_CHILDREN];
   long long carry = 0; /* survivors in the low half, complete children in the high half: one scan for both */
   long long cuts = 0, props = 0, revs = 0; /* per thread, reduced once at the end */
-  for (int base = 0; base < children; base += 1024) {
-    const int i = base + (int)threadIdx.x;
-    int status = -2;
-    if (i < children) {
-      status = res[i].status;
-      props += res[i].props;
-      revs += res[i].revisions;
-      cuts += status == -1;
+  constexpr int PER = 4; /* consecutive children per thread and tile */
+  for (int base = 0; base < children; base += 1024 * PER) {
+    const int first = base + (int)threadIdx.x * PER;
+    int status[PER];
+    long long sum = 0;
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+      const int i = first + q;
+      status[q] = -2;
+      if (i < children) {
+        const csgpu_result r = res[i];
+        status[q] = r.status;
+        props += r.props;
+        revs += r.revisions;
+        cuts += r.status == -1;
+      }
+      sum += (long long)(status[q] > 0) | ((long long)(status[q] == 0) << 32);
     }
     long long total;
-    const long long x = (long long)(status > 0) | ((long long)(status == 0) << 32);
-    const long long ex = carry + cs_block_excl_scan(x, s_part, &total);
-    if (i < children) {
-      if (status > 0) surv_list[ex & 0xffffffffll] = i;
-      if (status == 0) complete_list[ex >> 32] = i;
+    long long ex = carry + cs_block_excl_scan(sum, s_part, &total);
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+      if (status[q] > 0) surv_list[ex & 0xffffffffll] = first + q;
+      if (status[q] == 0) complete_list[ex >> 32] = first + q;
+      ex += (long long)(status[q] > 0) | ((long long)(status[q] == 0) << 32);
     }
     carry += total;
   }

@@ -414,17 +414,18 @@ __global__ __launch_bounds__(1024) void cs_expand_small(const cs_val *__restrict
   __shared__ long long s_part[16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x < C_PER_ITERATION) counters[threadIdx.x] = 0ull;
-  for (int p = wave; p < parents; p += 16) {
+  /* sixteen lanes per parent: all (at most 256) parents of the iteration in four passes of the workgroup */
+  for (int p = (int)threadIdx.x >> 4; p < parents; p += 64) {
     int var, count, skipped = 0;
     const cs_val *row = pool + (size_t)(first_row + p) * n;
-    cs_branch_seg<64>(row, n, lane, &var, &count);
+    cs_branch_seg<16>(row, n, (int)threadIdx.x & 15, &var, &count);
     unsigned a_lo, a_hi;
     if (cs_row_holes(H, row, first_row + p, n, var, &a_lo, &a_hi)) {
       const int allowed = __popc(a_lo) + __popc(a_hi);
       skipped = count - allowed;
       count = allowed;
     }
-    if (lane == 0) { s_var[p] = var; s_cnt[p] = count; s_skip[p] = skipped; }
+    if ((threadIdx.x & 15) == 0) { s_var[p] = var; s_cnt[p] = count; s_skip[p] = skipped; }
   }
   __syncthreads();
   long long total, skipped_total;
@@ -606,17 +607,18 @@ __global__ __launch_bounds__(1024) void cs_expand_burst(const cs_val *__restrict
   const int low_values_last = objective == CS_OBJ_MAX ? 0 : 1;
   const unsigned scramble =
       objective == CS_OBJ_ANY ? (unsigned)((unsigned long long)s_iter * 2654435761ull + 0x9e3779b9u) | 1u : 0u;
-  for (int p = wave; p < parents; p += 16) {
+  /* sixteen lanes per parent: all (at most 256) parents of the iteration in four passes of the workgroup */
+  for (int p = (int)threadIdx.x >> 4; p < parents; p += 64) {
     int var, count, skipped = 0;
     const cs_val *row = pool + (size_t)(first_row + p) * n;
-    cs_branch_seg<64>(row, n, lane, &var, &count);
+    cs_branch_seg<16>(row, n, (int)threadIdx.x & 15, &var, &count);
     unsigned a_lo, a_hi;
     if (cs_row_holes(H, row, first_row + p, n, var, &a_lo, &a_hi)) {
       const int allowed = __popc(a_lo) + __popc(a_hi);
       skipped = count - allowed;
       count = allowed;
     }
-    if (lane == 0) { s_var[p] = var; s_cnt[p] = count; s_skip[p] = skipped; }
+    if ((threadIdx.x & 15) == 0) { s_var[p] = var; s_cnt[p] = count; s_skip[p] = skipped; }
   }
   __syncthreads();
   long long total, skipped_total;

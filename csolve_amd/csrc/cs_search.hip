@@ -412,7 +412,6 @@ __global__ __launch_bounds__(1024) void cs_expand_small(const cs_val *__restrict
                                                         unsigned scramble, cs_holes H) {
   __shared__ int s_var[SMALL_PARENTS], s_cnt[SMALL_PARENTS], s_off[SMALL_PARENTS], s_skip[SMALL_PARENTS];
   __shared__ long long s_part[16];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x < C_PER_ITERATION) counters[threadIdx.x] = 0ull;
   /* sixteen lanes per parent: all (at most 256) parents of the iteration in four passes of the workgroup */
   for (int p = (int)threadIdx.x >> 4; p < parents; p += 64) {
@@ -438,8 +437,9 @@ __global__ __launch_bounds__(1024) void cs_expand_small(const cs_val *__restrict
     counters[C_SKIPPED] = (unsigned long long)skipped_total;
   }
   __syncthreads();
-  for (int p = wave; p < parents; p += 16)
-    cs_emit_seg<64>(pool, first_row + p, n, s_var[p], s_off[p], s_cnt[p], nodes, low_values_last, scramble, lane, H);
+  for (int p = (int)threadIdx.x >> 4; p < parents; p += 64)
+    cs_emit_seg<16>(pool, first_row + p, n, s_var[p], s_off[p], s_cnt[p], nodes, low_values_last, scramble,
+                    (int)threadIdx.x & 15, H);
 }
 
 
@@ -575,7 +575,6 @@ __global__ __launch_bounds__(1024) void cs_expand_burst(const cs_val *__restrict
   __shared__ long long s_part[16];
   __shared__ long long s_first, s_iter;
   __shared__ int s_parents;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x == 0) {
     const long long top = (long long)burst[B_TOP];
     /* a few parents while the pool is small (dive for a solution / an incumbent first), more once there is a
@@ -636,8 +635,9 @@ __global__ __launch_bounds__(1024) void cs_expand_burst(const cs_val *__restrict
     burst[B_CUTS] += (unsigned long long)skipped_total;
   }
   __syncthreads();
-  for (int p = wave; p < parents; p += 16)
-    cs_emit_seg<64>(pool, first_row + p, n, s_var[p], s_off[p], s_cnt[p], nodes, low_values_last, scramble, lane, H);
+  for (int p = (int)threadIdx.x >> 4; p < parents; p += 64)
+    cs_emit_seg<16>(pool, first_row + p, n, s_var[p], s_off[p], s_cnt[p], nodes, low_values_last, scramble,
+                    (int)threadIdx.x & 15, H);
 }
 
 /* cs_accept + cs_pick_best for the complete children of a small iteration, one workgroup, nothing read by the

@@ -304,7 +304,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch the timed steps one by one instead of as one hipGraph")
     ap.add_argument("--kernel", type=int, default=0, help="0 best, 1 general, 2 LDS-resident, 3 forbidden sets in LDS, 4 forbidden sets in registers, "
-                         "5 = 4 with several nodes per wave (at most 32 variables)")
+                         "5 = 4 with several nodes per wave (at most 32 variables), 6 clause-resident (small models)")
     ap.add_argument("--rebuild-sets", action="store_true", help="forbidden-set kernel without resident sets")
     ap.add_argument("--layout", choices=["intervals", "sets"], default="intervals",
                     help="intervals: {lo,hi} states with the forbidden sets next to them (default); sets: the states are "
@@ -373,7 +373,7 @@ def main():
         if forced in (0, 5) and model.qualifies(5) and args.layout == "intervals":
             kernel_name = "cs_propagate_ne_packed"
     else:
-        kernel_name = {1: "cs_propagate_events", 2: "cs_propagate_ne_lds"}[model.kernel()]
+        kernel_name = {1: "cs_propagate_events", 2: "cs_propagate_ne_lds", 6: "cs_propagate_clause_rounds"}[model.kernel()]
     n = model.n_vars
     info = model.device_info()
 

@@ -459,6 +459,16 @@ static const void *ne_packed_kernel(int n_vars, int nw, int s3) {
 #undef CS_PICK_S
 }
 
+/* kernel 6: clauses per lane (1, 2, 4) if every clause is a binary relation or a two-literal disjunction and
+ * there are at most 256 of them, else 0 */
+static int clause_rounds_cpl(const csgpu_model *m) {
+  if (m->img == NULL || m->has_tree_adj || m->img->n_clauses <= 0 || m->img->n_clauses > 4 * CS_WAVE) return 0;
+  for (int32_t c = 0; c < m->img->n_clauses; c++)
+    if (m->img->clause[4 * c] == CS_CL_TREE) return 0;
+  const int per = (m->img->n_clauses + CS_WAVE - 1) / CS_WAVE;
+  return per <= 1 ? 1 : (per <= 2 ? 2 : 4);
+}
+
 /* ---- finalize ---------------------------------------------------------------------- */
 
 extern "C" int csgpu_model_build_tables(csgpu_model *m) {
@@ -674,13 +684,15 @@ extern "C" int csgpu_model_finalize(csgpu_model *m) {
 }
 
 extern "C" int csgpu_model_set_kernel(csgpu_model *m, int which) {
-  if (m == NULL || which < 0 || which > 5) return set_err(CSGPU_E_ARG, "bad argument");
+  if (m == NULL || which < 0 || which > 6) return set_err(CSGPU_E_ARG, "bad argument");
   if (which >= 2) {
     if (!m->finalized) return set_err(CSGPU_E_STATE, "model is not finalized");
     if (which == 2 && !m->lds_waves) return set_err(CSGPU_E_LIMIT, "model does not qualify for the LDS-resident kernel");
     if (which == 3 && !m->fb_words) return set_err(CSGPU_E_LIMIT, "model does not qualify for the forbidden-set kernel");
     if (which == 4 && !m->dense_waves)
       return set_err(CSGPU_E_LIMIT, "model does not qualify for the register-resident forbidden-set kernel");
+    if (which == 6 && !clause_rounds_cpl(m))
+      return set_err(CSGPU_E_LIMIT, "model does not qualify for the clause-resident kernel (at most 256 binary / two-literal clauses)");
     if (which == 5 && !(m->dense_waves && packed_nodes_per_wave(m->fb_words, m->host->n_vars, m->img->dense_width)))
       return set_err(CSGPU_E_LIMIT, "model does not qualify for the several-nodes-per-wave kernel (at most 32 variables, 64 values)");
   }
@@ -695,6 +707,7 @@ extern "C" int csgpu_model_qualifies(const csgpu_model *m, int which) {
   case 2: return m->lds_waves != 0;
   case 3: return m->fb_words != 0;
   case 4: return m->dense_waves != 0;
+  case 6: return clause_rounds_cpl(m) != 0;
   case 5: return m->dense_waves != 0 && packed_nodes_per_wave(m->fb_words, m->host->n_vars, m->img->dense_width) != 0;
   default: return 0;
   }
@@ -873,7 +886,8 @@ extern "C" int csgpu_propagate_batch_sets(const csgpu_model *m, const uint64_t *
 extern "C" int csgpu_model_get_kernel(const csgpu_model *m) {
   if (m == NULL) return CSGPU_E_ARG;
   if (m->kernel_choice) return m->kernel_choice;
-  return m->lds_waves ? 2 : 1;
+  if (m->lds_waves) return 2;
+  return clause_rounds_cpl(m) ? 6 : 1;
 }
 
 /* ---- batched propagation ----------------------------------------------------------- */
@@ -932,7 +946,7 @@ extern "C" int csgpu_internal_propagate_objdev(const csgpu_model *m, const csgpu
       tab.obj_sense = sense;
     }
   }
-  if (m->kernel_choice >= 3 && tab.obj_var < 0)
+  if (m->kernel_choice >= 3 && m->kernel_choice <= 5 && tab.obj_var < 0)
     return csgpu_internal_propagate_fb(m, d_states_in, NULL, d_nodes, d_states_out, NULL, d_results, batch, d_batch, stream);
   const unsigned long long *bdev = (const unsigned long long *)d_batch;
   if (csgpu_model_get_kernel(m) == 2 && tab.obj_var < 0 && d_batch == NULL) {
@@ -951,6 +965,27 @@ extern "C" int csgpu_internal_propagate_objdev(const csgpu_model *m, const csgpu
     void *args[] = { &tab, &packed, &n_adj, &obits, &dmin, &in, &nodes, &out, &res, &nb };
     HIP_TRY(hipLaunchKernel(ne_lds_kernel(m->img->packed_width, m->host->n_vars), dim3((unsigned)grid), blk, args,
                             m->lds_bytes, s));
+    return CSGPU_OK;
+  }
+  if (csgpu_model_get_kernel(m) == 6) {
+    const size_t lds6 = ((((size_t)m->host->n_vars * sizeof(cs_val) + 16 + 15) & ~(size_t)15)) * CS_WAVES_PER_BLOCK;
+    int64_t blocks6 = (batch + CS_WAVES_PER_BLOCK - 1) / CS_WAVES_PER_BLOCK;
+    if (blocks6 > (int64_t)m->n_cus * 8 * 4) blocks6 = (int64_t)m->n_cus * 8 * 4;
+    switch (clause_rounds_cpl(m)) {
+    case 1:
+      hipLaunchKernelGGL((cs_propagate_clause_rounds<1>), dim3((unsigned)blocks6), dim3(CS_BLOCK), lds6, s, tab, in, nodes,
+                         out, res, (long long)batch, bdev);
+      break;
+    case 2:
+      hipLaunchKernelGGL((cs_propagate_clause_rounds<2>), dim3((unsigned)blocks6), dim3(CS_BLOCK), lds6, s, tab, in, nodes,
+                         out, res, (long long)batch, bdev);
+      break;
+    default:
+      hipLaunchKernelGGL((cs_propagate_clause_rounds<4>), dim3((unsigned)blocks6), dim3(CS_BLOCK), lds6, s, tab, in, nodes,
+                         out, res, (long long)batch, bdev);
+      break;
+    }
+    HIP_TRY(hipGetLastError());
     return CSGPU_OK;
   }
   if (m->has_tree_adj && m->k1_tab_bytes)

@@ -10,6 +10,7 @@
  *   cs_propagate_ne_regs  (4) models of at most 256 variables: sets and bounds in registers (the bench kernel),
  *                             also with the states carried as the sets alone
  *   cs_propagate_ne_packed(5) kernel 4 for at most 32 variables: two or four nodes per wave
+ *   cs_propagate_clause_rounds (6) at most 256 binary / two-literal clauses, resident in registers: all revised per round
  *   cs_propagate_sweeps, cs_eval_root, cs_eval_clauses, cs_sets_unpack: root phase, evaluation, layout helper
  *
  * Execution model of the general kernel (cs_propagate_events):
@@ -501,6 +502,122 @@ __global__ __launch_bounds__(CS_BLOCK) void cs_propagate_events(cs_tables T, con
     cs_wave_sync();
 
     /* wave totals */
+    int props = cx.props, revs = cx.revisions;
+    for (int off = 32; off > 0; off >>= 1) {
+      props += __shfl_xor(props, off);
+      revs += __shfl_xor(revs, off);
+    }
+    int open_vars = 0;
+    if (!failed) {
+      cs_val *dst = states_out + (size_t)node * n;
+      for (int v = lane; v < n; v += CS_WAVE) {
+        const cs_val d = dom[v];
+        dst[v] = d;
+        open_vars += __popcll(__ballot(d.lo != d.hi));
+      }
+    }
+    if (lane == 0) {
+      cs_node_out r;
+      r.status = failed ? -1 : open_vars;
+      r.props = props;
+      r.revisions = revs;
+      r.rounds = rounds;
+      results[node] = r;
+    }
+    cs_wave_sync();
+  }
+}
+
+/* ---- kernel 6: small models of binary / two-literal clauses, the clauses resident in registers ------
+ *
+ * The event-driven kernel walks the changed variables of a round one after the other (a stride of the wave per
+ * variable, each a chain of dependent LDS accesses): on a model of a few dozen clauses that walk IS the latency
+ * of a node -- 22 us per launch on schedule-10 however small the batch, which is what bounds an iteration of a
+ * MIN / MAX search.  Here every lane keeps up to CPL clause records (and the literals of its disjunctions) in
+ * registers for the whole kernel and a round revises ALL clauses at once; a round is one chain of LDS
+ * accesses.  Same fixpoints and verdicts (the revisions are monotone narrowings; the parent is a fixpoint, so
+ * revising a clause nothing touched is a no-op), PROPS counted the same way, order of narrowings different. */
+template <int CPL>
+__global__ __launch_bounds__(CS_BLOCK) void cs_propagate_clause_rounds(cs_tables T, const cs_val *__restrict__ states_in,
+                                                                       const cs_node_in *__restrict__ nodes,
+                                                                       cs_val *__restrict__ states_out,
+                                                                       cs_node_out *__restrict__ results, long long batch,
+                                                                       const unsigned long long *__restrict__ batch_dev) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
+  const int lane = threadIdx.x & (CS_WAVE - 1);
+  const int wave_in_block = threadIdx.x >> 6;
+  const int n = T.n_vars;
+  if (batch_dev != nullptr && (long long)*batch_dev < batch) batch = (long long)*batch_dev;
+  if ((long long)blockIdx.x * CS_WAVES_PER_BLOCK >= batch) return;
+  const size_t slice_al = ((size_t)n * sizeof(cs_val) + 16 + 15) & ~(size_t)15;
+  cs_val *dom = (cs_val *)(cs_lds + wave_in_block * slice_al);
+  unsigned *flag = (unsigned *)(dom + n); /* [0]: something changed this round */
+
+  int4 rec[CPL], lit0[CPL], lit1[CPL];
+#pragma unroll
+  for (int q = 0; q < CPL; q++) {
+    const int c = lane + q * CS_WAVE;
+    rec[q] = c < T.n_clauses ? T.clause[c] : make_int4(CS_CL_SKIP, 0, 0, 0);
+    lit0[q] = rec[q].x == CS_CL_OR2 ? T.lit[rec[q].y] : make_int4(0, 0, 0, 0);
+    lit1[q] = rec[q].x == CS_CL_OR2 ? T.lit[rec[q].y + 1] : make_int4(0, 0, 0, 0);
+  }
+
+  const long long waves_total = (long long)gridDim.x * CS_WAVES_PER_BLOCK;
+  for (long long node = (long long)blockIdx.x * CS_WAVES_PER_BLOCK + wave_in_block; node < batch; node += waves_total) {
+    const cs_node_in nin = nodes[node];
+    const cs_val *src = states_in + (size_t)nin.parent * n;
+    for (int v = lane; v < n; v += CS_WAVE) dom[v] = src[v];
+    cs_wave_sync();
+    if (lane == 0) {
+      /* step_enter: bind(var, VALUE(v)) -- csolve.c:294-304; not counted in PROPS */
+      if (nin.var >= 0) dom[nin.var] = cs_interval(nin.lo, nin.hi);
+      if (T.obj_var >= 0) { /* untrailed tightening of "<obj>" by the incumbent (objective.c:101-126) */
+        int obj_lo = T.obj_lo, obj_hi = T.obj_hi;
+        if (T.obj_best_dev != nullptr) {
+          const int best = *T.obj_best_dev;
+          if (T.obj_sense == 1) obj_hi = cs_add(best, cs_neg(1));
+          else obj_lo = cs_add(best, 1);
+        }
+        const cs_val d = dom[T.obj_var];
+        dom[T.obj_var] = cs_interval(cs_max(d.lo, obj_lo), cs_min(d.hi, obj_hi));
+      }
+    }
+    cs_wave_sync();
+
+    cs_ctx cx;
+    cx.dom = dom;
+    cx.mark = flag;
+    cx.mark_is_flag = 1;
+    cx.fail = 0;
+    cx.props = 0;
+    cx.revisions = 0;
+    int rounds = 0, failed = 0;
+    for (;;) {
+      if (lane == 0) flag[0] = 0u;
+      /* an interval emptied by the assignment, the incumbent or racing updates of lo and hi */
+      for (int v = lane; v < n; v += CS_WAVE)
+        if (dom[v].lo > dom[v].hi) cx.fail = 1;
+      cs_wave_sync();
+#pragma unroll
+      for (int q = 0; q < CPL; q++) {
+        if (cx.fail) break;
+        const int4 r = rec[q];
+        if (r.x == CS_CL_NE) {
+          cs_ne_revise(cx, r.y, r.z, r.w);
+        } else if (r.x == CS_CL_EQ || r.x == CS_CL_LT) {
+          cs_lin_revise(cx, r.y, r.z, r.w, r.x == CS_CL_EQ ? CS_REL_EQ : CS_REL_LT);
+        } else if (r.x == CS_CL_OR2) {
+          const int4 lits[2] = { lit0[q], lit1[q] };
+          cs_or2_revise(cx, lits);
+        }
+      }
+      cs_wave_sync();
+      if (__any(cx.fail)) { failed = 1; break; }
+      if (flag[0] == 0u) break;
+      rounds++;
+    }
+    cs_wave_sync();
+
     int props = cx.props, revs = cx.revisions;
     for (int off = 32; off > 0; off >>= 1) {
       props += __shfl_xor(props, off);

@@ -137,19 +137,21 @@ int csgpu_propagate_batch_sets(const csgpu_model *m, const uint64_t *d_sets_in, 
  * models, root intervals of at most 256 values), 4 = its register-resident variant (additionally
  * at most 256 variables and a dense pair table that fits in LDS), 5 = kernel 4 with two or four
  * nodes per wavefront (additionally at most 32 variables of at most 64 values; 4 then means one
- * node per wavefront); CSGPU_E_LIMIT if the model does not qualify.  All compute the same results;
- * tests run every parity case through each of them.
+ * node per wavefront), 6 = the clause-resident kernel for small models (at most 256 clauses, all of
+ * them binary relations or two-literal disjunctions: every lane keeps its clauses in registers and
+ * a round revises all of them); CSGPU_E_LIMIT if the model does not qualify.  All compute the same
+ * results; tests run every parity case through each of them.
  * Automatic: csgpu_propagate_batch_fb uses 5 when the model qualifies, else 4, else 3;
- * csgpu_propagate_batch uses 2, else 1. */
+ * csgpu_propagate_batch uses 2, else 6, else 1. */
 int csgpu_model_set_kernel(csgpu_model *m, int which);
 /* Process-wide switch for models finalized afterwards: 1 (default) = EQ / LT / two-literal OR clauses
  * over `VAR` or `VAR + constant` operands are revised by direct bound propagation (schedule.txt-style
  * models then need no expression-tree interpreter); 0 = they stay expression trees.  Same fixpoints
  * either way (tests compare the two). */
 void csgpu_set_linear_fast_paths(int on);
-/* 1 if the finalized model can run kernel `which` (1..5), else 0 */
+/* 1 if the finalized model can run kernel `which` (1..6), else 0 */
 int csgpu_model_qualifies(const csgpu_model *m, int which);
-/* which kernel csgpu_propagate_batch will launch: 1, 2 or 3 (see above) */
+/* which kernel csgpu_propagate_batch will launch (see above) */
 int csgpu_model_get_kernel(const csgpu_model *m);
 
 /* ---- batched propagation (the hot path) ----

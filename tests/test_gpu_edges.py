@@ -16,14 +16,14 @@ def _oracle_for(text, model):
     return Oracle(om)
 
 
-def _check(text, nodes_fn, kernels=(1, 2, 3, 4, 5), batch_sizes=(1, 3, 16, 17, 100)):
+def _check(text, nodes_fn, kernels=(1, 2, 3, 4, 5, 6), batch_sizes=(1, 3, 16, 17, 100)):
     from csolve_amd.solver import solve_root
     model = solve_root(text)
     orc = _oracle_for(text, model)
     n = model.n_vars
     root = model.domains()
     rng = np.random.default_rng(5)
-    eligible = [k for k in (1, 2, 3, 4, 5) if model.qualifies(k)]
+    eligible = [k for k in (1, 2, 3, 4, 5, 6) if model.qualifies(k)]
     ran = []
     for k in kernels:
         if k not in eligible:
@@ -89,11 +89,11 @@ def test_negative_domains_and_offsets():
 
 
 def test_wide_domains_fall_back_from_the_forbidden_set_kernel():
-    """root intervals wider than 256 values: no forbidden-set kernel, the unit-shaving kernels
-    handle them (and give the same results)"""
+    """root intervals wider than 256 values: no forbidden-set kernel, the unit-shaving kernels and the
+    clause-resident kernel handle them (and give the same results)"""
     text = "ANY; all_different(a, b, c); 0 <= a; a <= 1000; 0 <= b; b <= 1000; 500 <= c; c <= 2000; a + 1 != c;"
     model, ran = _check(text, _value_nodes)
-    assert model.forbidden_words() == 0 and ran == [1, 2]
+    assert model.forbidden_words() == 0 and ran == [1, 2, 6]
 
 
 def test_128_and_256_value_domains_use_wider_sets():

@@ -40,6 +40,8 @@ def _kernels(model):
         ks.append(4)  # the same with the sets in registers
     if model.qualifies(5):
         ks.append(5)  # several nodes per wave (at most 32 variables)
+    if model.qualifies(6):
+        ks.append(6)  # small models: clauses resident in registers, all revised per round
     return ks
 
 

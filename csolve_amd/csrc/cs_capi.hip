@@ -459,12 +459,9 @@ static const void *ne_packed_kernel(int n_vars, int nw, int s3) {
 #undef CS_PICK_S
 }
 
-/* kernel 6: clauses per lane (1, 2, 4) if every clause is a binary relation or a two-literal disjunction and
- * there are at most 256 of them, else 0 */
+/* kernel 6: clauses per lane (1, 2, 4) if the model has at most 256 clauses, else 0 */
 static int clause_rounds_cpl(const csgpu_model *m) {
-  if (m->img == NULL || m->has_tree_adj || m->img->n_clauses <= 0 || m->img->n_clauses > 4 * CS_WAVE) return 0;
-  for (int32_t c = 0; c < m->img->n_clauses; c++)
-    if (m->img->clause[4 * c] == CS_CL_TREE) return 0;
+  if (m->img == NULL || m->img->n_clauses <= 0 || m->img->n_clauses > 4 * CS_WAVE) return 0;
   const int per = (m->img->n_clauses + CS_WAVE - 1) / CS_WAVE;
   return per <= 1 ? 1 : (per <= 2 ? 2 : 4);
 }
@@ -692,7 +689,7 @@ extern "C" int csgpu_model_set_kernel(csgpu_model *m, int which) {
     if (which == 4 && !m->dense_waves)
       return set_err(CSGPU_E_LIMIT, "model does not qualify for the register-resident forbidden-set kernel");
     if (which == 6 && !clause_rounds_cpl(m))
-      return set_err(CSGPU_E_LIMIT, "model does not qualify for the clause-resident kernel (at most 256 binary / two-literal clauses)");
+      return set_err(CSGPU_E_LIMIT, "model does not qualify for the clause-resident kernel (at most 256 clauses)");
     if (which == 5 && !(m->dense_waves && packed_nodes_per_wave(m->fb_words, m->host->n_vars, m->img->dense_width)))
       return set_err(CSGPU_E_LIMIT, "model does not qualify for the several-nodes-per-wave kernel (at most 32 variables, 64 values)");
   }
@@ -971,20 +968,15 @@ extern "C" int csgpu_internal_propagate_objdev(const csgpu_model *m, const csgpu
     const size_t lds6 = ((((size_t)m->host->n_vars * sizeof(cs_val) + 16 + 15) & ~(size_t)15)) * CS_WAVES_PER_BLOCK;
     int64_t blocks6 = (batch + CS_WAVES_PER_BLOCK - 1) / CS_WAVES_PER_BLOCK;
     if (blocks6 > (int64_t)m->n_cus * 8 * 4) blocks6 = (int64_t)m->n_cus * 8 * 4;
+#define CS_LAUNCH6(CPL, TREE)                                                                       \
+  hipLaunchKernelGGL((cs_propagate_clause_rounds<CPL, TREE>), dim3((unsigned)blocks6), dim3(CS_BLOCK), lds6, s, tab, in, \
+                     nodes, out, res, (long long)batch, bdev)
     switch (clause_rounds_cpl(m)) {
-    case 1:
-      hipLaunchKernelGGL((cs_propagate_clause_rounds<1>), dim3((unsigned)blocks6), dim3(CS_BLOCK), lds6, s, tab, in, nodes,
-                         out, res, (long long)batch, bdev);
-      break;
-    case 2:
-      hipLaunchKernelGGL((cs_propagate_clause_rounds<2>), dim3((unsigned)blocks6), dim3(CS_BLOCK), lds6, s, tab, in, nodes,
-                         out, res, (long long)batch, bdev);
-      break;
-    default:
-      hipLaunchKernelGGL((cs_propagate_clause_rounds<4>), dim3((unsigned)blocks6), dim3(CS_BLOCK), lds6, s, tab, in, nodes,
-                         out, res, (long long)batch, bdev);
-      break;
+    case 1: if (m->has_tree_adj) CS_LAUNCH6(1, true); else CS_LAUNCH6(1, false); break;
+    case 2: if (m->has_tree_adj) CS_LAUNCH6(2, true); else CS_LAUNCH6(2, false); break;
+    default: if (m->has_tree_adj) CS_LAUNCH6(4, true); else CS_LAUNCH6(4, false); break;
     }
+#undef CS_LAUNCH6
     HIP_TRY(hipGetLastError());
     return CSGPU_OK;
   }

@@ -10,7 +10,7 @@
  *   cs_propagate_ne_regs  (4) models of at most 256 variables: sets and bounds in registers (the bench kernel),
  *                             also with the states carried as the sets alone
  *   cs_propagate_ne_packed(5) kernel 4 for at most 32 variables: two or four nodes per wave
- *   cs_propagate_clause_rounds (6) at most 256 binary / two-literal clauses, resident in registers: all revised per round
+ *   cs_propagate_clause_rounds (6) at most 256 clauses, resident in registers: all revised per round
  *   cs_propagate_sweeps, cs_eval_root, cs_eval_clauses, cs_sets_unpack: root phase, evaluation, layout helper
  *
  * Execution model of the general kernel (cs_propagate_events):
@@ -535,9 +535,10 @@ __global__ __launch_bounds__(CS_BLOCK) void cs_propagate_events(cs_tables T, con
  * of a node -- 22 us per launch on schedule-10 however small the batch, which is what bounds an iteration of a
  * MIN / MAX search.  Here every lane keeps up to CPL clause records (and the literals of its disjunctions) in
  * registers for the whole kernel and a round revises ALL clauses at once; a round is one chain of LDS
- * accesses.  Same fixpoints and verdicts (the revisions are monotone narrowings; the parent is a fixpoint, so
+ * accesses.  Expression-tree clauses (HAS_TREE) take one lane each: once per round instead of once per changed
+ * variable of the tree.  Same fixpoints and verdicts (the revisions are monotone narrowings; the parent is a fixpoint, so
  * revising a clause nothing touched is a no-op), PROPS counted the same way, order of narrowings different. */
-template <int CPL>
+template <int CPL, bool HAS_TREE>
 __global__ __launch_bounds__(CS_BLOCK) void cs_propagate_clause_rounds(cs_tables T, const cs_val *__restrict__ states_in,
                                                                        const cs_node_in *__restrict__ nodes,
                                                                        cs_val *__restrict__ states_out,
@@ -609,6 +610,9 @@ __global__ __launch_bounds__(CS_BLOCK) void cs_propagate_clause_rounds(cs_tables
         } else if (r.x == CS_CL_OR2) {
           const int4 lits[2] = { lit0[q], lit1[q] };
           cs_or2_revise(cx, lits);
+        } else if (HAS_TREE && r.x == CS_CL_TREE) {
+          cs_tree_scratch S; /* one lane interprets one expression tree: all trees of the model side by side */
+          cs_tree_revise(T, r.y, cx, S);
         }
       }
       cs_wave_sync();

@@ -137,9 +137,8 @@ int csgpu_propagate_batch_sets(const csgpu_model *m, const uint64_t *d_sets_in, 
  * models, root intervals of at most 256 values), 4 = its register-resident variant (additionally
  * at most 256 variables and a dense pair table that fits in LDS), 5 = kernel 4 with two or four
  * nodes per wavefront (additionally at most 32 variables of at most 64 values; 4 then means one
- * node per wavefront), 6 = the clause-resident kernel for small models (at most 256 clauses, all of
- * them binary relations or two-literal disjunctions: every lane keeps its clauses in registers and
- * a round revises all of them); CSGPU_E_LIMIT if the model does not qualify.  All compute the same
+ * node per wavefront), 6 = the clause-resident kernel for small models (at most 256 clauses: every
+ * lane keeps its clauses in registers and a round revises all of them); CSGPU_E_LIMIT if the model does not qualify.  All compute the same
  * results; tests run every parity case through each of them.
  * Automatic: csgpu_propagate_batch_fb uses 5 when the model qualifies, else 4, else 3;
  * csgpu_propagate_batch uses 2, else 6, else 1. */

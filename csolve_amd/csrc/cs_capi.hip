@@ -459,11 +459,11 @@ static const void *ne_packed_kernel(int n_vars, int nw, int s3) {
 #undef CS_PICK_S
 }
 
-/* kernel 6: clauses per lane (1, 2, 4) if the model has at most 256 clauses, else 0 */
+/* kernel 6: clauses per lane (1, 2, 4, 8) if the model has at most 512 clauses, else 0 */
 static int clause_rounds_cpl(const csgpu_model *m) {
-  if (m->img == NULL || m->img->n_clauses <= 0 || m->img->n_clauses > 4 * CS_WAVE) return 0;
+  if (m->img == NULL || m->img->n_clauses <= 0 || m->img->n_clauses > 8 * CS_WAVE) return 0;
   const int per = (m->img->n_clauses + CS_WAVE - 1) / CS_WAVE;
-  return per <= 1 ? 1 : (per <= 2 ? 2 : 4);
+  return per <= 1 ? 1 : (per <= 2 ? 2 : (per <= 4 ? 4 : 8));
 }
 
 /* ---- finalize ---------------------------------------------------------------------- */
@@ -689,7 +689,7 @@ extern "C" int csgpu_model_set_kernel(csgpu_model *m, int which) {
     if (which == 4 && !m->dense_waves)
       return set_err(CSGPU_E_LIMIT, "model does not qualify for the register-resident forbidden-set kernel");
     if (which == 6 && !clause_rounds_cpl(m))
-      return set_err(CSGPU_E_LIMIT, "model does not qualify for the clause-resident kernel (at most 256 clauses)");
+      return set_err(CSGPU_E_LIMIT, "model does not qualify for the clause-resident kernel (at most 512 clauses)");
     if (which == 5 && !(m->dense_waves && packed_nodes_per_wave(m->fb_words, m->host->n_vars, m->img->dense_width)))
       return set_err(CSGPU_E_LIMIT, "model does not qualify for the several-nodes-per-wave kernel (at most 32 variables, 64 values)");
   }
@@ -884,7 +884,8 @@ extern "C" int csgpu_model_get_kernel(const csgpu_model *m) {
   if (m == NULL) return CSGPU_E_ARG;
   if (m->kernel_choice) return m->kernel_choice;
   if (m->lds_waves) return 2;
-  return clause_rounds_cpl(m) ? 6 : 1;
+  const int cpl = clause_rounds_cpl(m);
+  return cpl >= 1 && cpl <= 4 ? 6 : 1; /* 8 clauses per lane: kernel 6 for small batches only, see below */
 }
 
 /* ---- batched propagation ----------------------------------------------------------- */
@@ -964,7 +965,14 @@ extern "C" int csgpu_internal_propagate_objdev(const csgpu_model *m, const csgpu
                             m->lds_bytes, s));
     return CSGPU_OK;
   }
-  if (csgpu_model_get_kernel(m) == 6) {
+  /* kernel 6 when asked for; automatically for models of at most 256 clauses (faster at every batch size
+   * measured), and with 257-512 clauses for small batches only (lower latency, 14 us against 21 us per launch
+   * on schedule-20, but less throughput: 215 us against 122 us for 65,536 nodes) -- the search engine's
+   * device-counted batches are small by construction */
+  const int cpl6 = clause_rounds_cpl(m);
+  const int use6 = m->kernel_choice == 6 ||
+                   (m->kernel_choice == 0 && !m->lds_waves && cpl6 != 0 && (cpl6 <= 4 || d_batch != NULL || batch <= 8192));
+  if (use6) {
     const size_t lds6 = ((((size_t)m->host->n_vars * sizeof(cs_val) + 16 + 15) & ~(size_t)15)) * CS_WAVES_PER_BLOCK;
     int64_t blocks6 = (batch + CS_WAVES_PER_BLOCK - 1) / CS_WAVES_PER_BLOCK;
     if (blocks6 > (int64_t)m->n_cus * 8 * 4) blocks6 = (int64_t)m->n_cus * 8 * 4;
@@ -974,7 +982,8 @@ extern "C" int csgpu_internal_propagate_objdev(const csgpu_model *m, const csgpu
     switch (clause_rounds_cpl(m)) {
     case 1: if (m->has_tree_adj) CS_LAUNCH6(1, true); else CS_LAUNCH6(1, false); break;
     case 2: if (m->has_tree_adj) CS_LAUNCH6(2, true); else CS_LAUNCH6(2, false); break;
-    default: if (m->has_tree_adj) CS_LAUNCH6(4, true); else CS_LAUNCH6(4, false); break;
+    case 4: if (m->has_tree_adj) CS_LAUNCH6(4, true); else CS_LAUNCH6(4, false); break;
+    default: if (m->has_tree_adj) CS_LAUNCH6(8, true); else CS_LAUNCH6(8, false); break;
     }
 #undef CS_LAUNCH6
     HIP_TRY(hipGetLastError());

@@ -562,6 +562,102 @@ __global__ __launch_bounds__(1024) void cs_classify_small(const csgpu_result *__
   }
 }
 
+/* cs_accept + cs_pick_best for the complete children of a small iteration, by one workgroup, nothing read by the
+ * host: counts the solutions, moves the incumbent, keeps a state that attains it (and, ANY: the first one).
+ * Called by every thread of a workgroup of at least 256 threads (the first 256 work; uniform control flow). */
+__device__ __forceinline__ void cs_accept_block(const cs_val *__restrict__ child_states, const int *__restrict__ list,
+                                                const int *__restrict__ truth, int n, int objective, int obj_var,
+                                                unsigned long long *__restrict__ counters,
+                                                unsigned long long *__restrict__ burst, int32_t *__restrict__ solutions,
+                                                long long max_solutions, int32_t *__restrict__ best_solution) {
+  __shared__ long long s_key[256];
+  __shared__ int s_cnt[256];
+  __shared__ int s_pick;
+  const int count = (int)counters[C_COMPLETE];
+  if (count == 0) return; /* uniform */
+  const int t = (int)threadIdx.x;
+  const bool opt = objective == CS_OBJ_MIN || objective == CS_OBJ_MAX;
+  /* key: (objective value, made "smaller is better") << 32 | child index: the minimum is the best value and,
+   * among equals, the first child */
+  long long key = 0x7fffffffffffffffll;
+  int cnt = 0;
+  if (t < 256)
+    for (int i = t; i < count; i += 256) {
+      if (truth[i] != 1) continue;
+      cnt++;
+      long long val = 0;
+      if (opt) {
+        const cs_val o = child_states[(size_t)list[i] * n + obj_var];
+        val = objective == CS_OBJ_MIN ? (long long)o.lo : -(long long)o.hi;
+      }
+      const long long k = val * 4294967296ll + (long long)i;
+      key = k < key ? k : key;
+      if (objective != CS_OBJ_ANY && counters[C_STORED] < (unsigned long long)max_solutions) {
+        const unsigned long long slot = atomicAdd(&counters[C_STORED], 1ull);
+        if (slot < (unsigned long long)max_solutions)
+          for (int v = 0; v < n; v++) solutions[(size_t)slot * n + v] = child_states[(size_t)list[i] * n + v].lo;
+      }
+    }
+  if (t < 256) {
+    s_key[t] = key;
+    s_cnt[t] = cnt;
+  }
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) {
+    if (t < d) {
+      s_key[t] = s_key[t + d] < s_key[t] ? s_key[t + d] : s_key[t];
+      s_cnt[t] += s_cnt[t + d];
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    s_pick = -1;
+    const int accepted = s_cnt[0];
+    if (accepted > 0) {
+      const long long best_key = s_key[0];
+      const int idx = (int)(best_key & 0xffffffffll);
+      if (objective == CS_OBJ_ANY) {
+        /* found_any (csolve.c:207-209): exactly one solution is accepted, the first in child order */
+        if (counters[C_STORED] == 0ull) {
+          counters[C_SOLUTIONS] += 1ull;
+          counters[C_STORED] = 1ull;
+          s_pick = idx;
+        }
+      } else {
+        counters[C_SOLUTIONS] += (unsigned long long)accepted;
+        if (opt) {
+          const long long v = (best_key - (long long)idx) / 4294967296ll;
+          const int val = objective == CS_OBJ_MIN ? (int)v : (int)-v;
+          int *best = (int *)&counters[C_BEST];
+          if (objective == CS_OBJ_MIN ? val < *best : val > *best) {
+            *best = val;
+            burst[B_IMPROVED] = 1ull;
+            s_pick = idx;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int pick = s_pick;
+  if (pick >= 0 && t < 256) {
+    int32_t *out = objective == CS_OBJ_ANY ? solutions : best_solution;
+    for (int v = t; v < n; v += 256) out[v] = child_states[(size_t)list[pick] * n + v].lo;
+  }
+  __syncthreads();
+}
+
+/* the accept of the LAST iteration of a burst (the others run at the head of the next cs_expand_burst) */
+__global__ __launch_bounds__(256) void cs_accept_burst(const cs_val *__restrict__ child_states, const int *__restrict__ list,
+                                                       const int *__restrict__ truth, int n, int objective, int obj_var,
+                                                       unsigned long long *__restrict__ counters,
+                                                       unsigned long long *__restrict__ burst,
+                                                       int32_t *__restrict__ solutions, long long max_solutions,
+                                                       int32_t *__restrict__ best_solution) {
+  cs_accept_block(child_states, list, truth, n, objective, obj_var, counters, burst, solutions, max_solutions, best_solution);
+  if (threadIdx.x == 0) counters[C_COMPLETE] = 0ull; /* accepted: the next burst's first expansion must not do it again */
+}
+
 /* ---- device-driven iterations: what the host does around a small iteration, on the device ----
  * cs_expand_burst = the head of one_iteration (how many parents, does it fit) + cs_expand_small; the pool top,
  * the iteration budget and the running totals are in `burst`.  An iteration with nothing to do (pool empty,
@@ -570,11 +666,19 @@ __global__ __launch_bounds__(1024) void cs_expand_burst(const cs_val *__restrict
                                                         unsigned long long *__restrict__ counters,
                                                         unsigned long long *__restrict__ burst, int objective,
                                                         long long max_width, long long cap, long long room_limit,
-                                                        cs_holes H) {
+                                                        cs_holes H, const cs_val *__restrict__ child_states,
+                                                        const int *__restrict__ complete_list,
+                                                        const int *__restrict__ truth, int obj_var,
+                                                        int32_t *__restrict__ solutions, long long max_solutions,
+                                                        int32_t *__restrict__ best_solution) {
   __shared__ int s_var[SMALL_PARENTS], s_cnt[SMALL_PARENTS], s_off[SMALL_PARENTS], s_skip[SMALL_PARENTS];
   __shared__ long long s_part[16];
   __shared__ long long s_first, s_iter;
   __shared__ int s_parents;
+  /* first the accept of the previous iteration's complete children (their root evaluation has run): it decides
+   * whether ANY is done and moves the incumbent this iteration's fixpoints will see */
+  cs_accept_block(child_states, complete_list, truth, n, objective, obj_var, counters, burst, solutions, max_solutions,
+                  best_solution);
   if (threadIdx.x == 0) {
     const long long top = (long long)burst[B_TOP];
     /* a few parents while the pool is small (dive for a solution / an incumbent first), more once there is a
@@ -638,86 +742,6 @@ __global__ __launch_bounds__(1024) void cs_expand_burst(const cs_val *__restrict
   for (int p = (int)threadIdx.x >> 4; p < parents; p += 64)
     cs_emit_seg<16>(pool, first_row + p, n, s_var[p], s_off[p], s_cnt[p], nodes, low_values_last, scramble,
                     (int)threadIdx.x & 15, H);
-}
-
-/* cs_accept + cs_pick_best for the complete children of a small iteration, one workgroup, nothing read by the
- * host: counts the solutions, moves the incumbent, keeps a state that attains it (and, ANY: the first one) */
-__global__ __launch_bounds__(256) void cs_accept_burst(const cs_val *__restrict__ child_states, const int *__restrict__ list,
-                                                       const int *__restrict__ truth, int n, int objective, int obj_var,
-                                                       unsigned long long *__restrict__ counters,
-                                                       unsigned long long *__restrict__ burst,
-                                                       int32_t *__restrict__ solutions, long long max_solutions,
-                                                       int32_t *__restrict__ best_solution) {
-  __shared__ long long s_key[256];
-  __shared__ int s_cnt[256];
-  __shared__ int s_pick;
-  const int count = (int)counters[C_COMPLETE];
-  if (count == 0) return;
-  const int t = (int)threadIdx.x;
-  const bool opt = objective == CS_OBJ_MIN || objective == CS_OBJ_MAX;
-  /* key: (objective value, made "smaller is better") << 32 | child index: the minimum is the best value and,
-   * among equals, the first child */
-  long long key = 0x7fffffffffffffffll;
-  int cnt = 0;
-  for (int i = t; i < count; i += 256) {
-    if (truth[i] != 1) continue;
-    cnt++;
-    long long val = 0;
-    if (opt) {
-      const cs_val o = child_states[(size_t)list[i] * n + obj_var];
-      val = objective == CS_OBJ_MIN ? (long long)o.lo : -(long long)o.hi;
-    }
-    const long long k = val * 4294967296ll + (long long)i;
-    key = k < key ? k : key;
-    if (objective != CS_OBJ_ANY && counters[C_STORED] < (unsigned long long)max_solutions) {
-      const unsigned long long slot = atomicAdd(&counters[C_STORED], 1ull);
-      if (slot < (unsigned long long)max_solutions)
-        for (int v = 0; v < n; v++) solutions[(size_t)slot * n + v] = child_states[(size_t)list[i] * n + v].lo;
-    }
-  }
-  s_key[t] = key;
-  s_cnt[t] = cnt;
-  __syncthreads();
-  for (int d = 128; d > 0; d >>= 1) {
-    if (t < d) {
-      s_key[t] = s_key[t + d] < s_key[t] ? s_key[t + d] : s_key[t];
-      s_cnt[t] += s_cnt[t + d];
-    }
-    __syncthreads();
-  }
-  if (t == 0) {
-    s_pick = -1;
-    const int accepted = s_cnt[0];
-    if (accepted > 0) {
-      const long long best_key = s_key[0];
-      const int idx = (int)(best_key & 0xffffffffll);
-      if (objective == CS_OBJ_ANY) {
-        /* found_any (csolve.c:207-209): exactly one solution is accepted, the first in child order */
-        if (counters[C_STORED] == 0ull) {
-          counters[C_SOLUTIONS] += 1ull;
-          counters[C_STORED] = 1ull;
-          s_pick = idx;
-        }
-      } else {
-        counters[C_SOLUTIONS] += (unsigned long long)accepted;
-        if (opt) {
-          const long long v = (best_key - (long long)idx) / 4294967296ll;
-          const int val = objective == CS_OBJ_MIN ? (int)v : (int)-v;
-          int *best = (int *)&counters[C_BEST];
-          if (objective == CS_OBJ_MIN ? val < *best : val > *best) {
-            *best = val;
-            burst[B_IMPROVED] = 1ull;
-            s_pick = idx;
-          }
-        }
-      }
-    }
-  }
-  __syncthreads();
-  const int pick = s_pick;
-  if (pick < 0) return;
-  int32_t *out = objective == CS_OBJ_ANY ? solutions : best_solution;
-  for (int v = t; v < n; v += 256) out[v] = child_states[(size_t)list[pick] * n + v].lo;
 }
 
 /* copy survivor k (child surv_list[k]) into pool row new_top + k: a workgroup takes cpb (at most SB) consecutive
@@ -1329,7 +1353,9 @@ static int enqueue_burst(csgpu_search *s, hipStream_t st) {
   while (cpb > 4 && bound / cpb < 2048) cpb >>= 1;
   for (int it = 0; it < BURST_ITERATIONS; it++) {
     hipLaunchKernelGGL(cs_expand_burst, dim3(1), dim3(1024), 0, st, s->pool, n, s->d_nodes, s->d_counters, s->d_burst,
-                       s->objective, (long long)s->max_width, (long long)s->cap, room_limit, s->holes);
+                       s->objective, (long long)s->max_width, (long long)s->cap, room_limit, s->holes,
+                       (const cs_val *)s->d_child_states, (const int *)s->d_complete_list, (const int *)s->d_truth,
+                       s->obj_var, s->d_solutions, (long long)s->max_solutions, s->d_best_solution);
     int rc;
     if (s->fw > 0)
       rc = csgpu_internal_propagate_fb(s->m, (const csgpu_val *)s->pool, (const uint64_t *)s->pool_forb, s->d_nodes,
@@ -1348,10 +1374,11 @@ static int enqueue_burst(csgpu_search *s, hipStream_t st) {
     rc = csgpu_internal_eval_list(s->m, (const csgpu_val *)s->d_child_states, s->d_complete_list,
                                   (const uint64_t *)(s->d_counters + C_COMPLETE), bound, s->d_truth, st);
     if (rc != CSGPU_OK) return rc;
-    hipLaunchKernelGGL(cs_accept_burst, dim3(1), dim3(256), 0, st, s->d_child_states, s->d_complete_list, s->d_truth, n,
-                       s->objective, s->obj_var, s->d_counters, s->d_burst, s->d_solutions, (long long)s->max_solutions,
-                       s->d_best_solution);
   }
+  /* the last iteration's accept (the others ran at the head of the following expansion) */
+  hipLaunchKernelGGL(cs_accept_burst, dim3(1), dim3(256), 0, st, s->d_child_states, s->d_complete_list, s->d_truth, n,
+                     s->objective, s->obj_var, s->d_counters, s->d_burst, s->d_solutions, (long long)s->max_solutions,
+                     s->d_best_solution);
   HIP_OK(hipGetLastError());
   return CSGPU_OK;
 }

@@ -33,6 +33,16 @@ struct cs_holes {
   const int *root_lo;
 };
 
+/* what the branching step decides for a parent and the emitting step needs (32 bytes per parent) */
+struct cs_choice {
+  int var;             /* -1: no open variable */
+  int lo, hi;          /* the branching variable's interval */
+  int count;           /* children that are launched */
+  unsigned a_lo, a_hi; /* holes != 0: bit j <=> value lo + j is a child */
+  int holes;           /* the parent's set was consulted: only the values it allows become children */
+  int skipped;         /* values of the interval cut without a launch */
+};
+
 /* state of the device-driven iterations, in device memory between the kernels of a burst */
 enum { B_TOP = 0, B_BUDGET, B_LIMIT, B_LIMIT_MAX, B_ITER_BASE, B_ITERS, B_NODES, B_CUTS, B_PROPS, B_REVS, B_PEAK, B_ERROR,
        B_SCATTER_BASE, B_IMPROVED, B_COUNT };
@@ -50,7 +60,8 @@ struct csgpu_search {
   int fw;
   unsigned long long *pool_forb, *d_child_forb;
   csgpu_node *d_rebuild_nodes;
-  int *d_branch_var, *d_child_count, *d_child_off /* per workgroup of cs_branch */, *d_block_sum, *d_block_skip;
+  cs_choice *d_choice; /* per parent: what cs_branch decided */
+  int *d_child_off /* per workgroup of cs_branch */, *d_block_sum, *d_block_skip;
   csgpu_node *d_nodes;
   cs_val *d_child_states, *d_complete_states;
   csgpu_result *d_results;
@@ -105,53 +116,88 @@ __device__ __forceinline__ void cs_allowed_values(unsigned long long forb, int r
   *a_hi = x_hi;
 }
 
-/* -> 1 and the mask of allowed values if the holes of variable `var` of this row may be skipped */
-__device__ __forceinline__ int cs_row_holes(const cs_holes &H, const cs_val *__restrict__ row, long long row_index, int n,
-                                            int var, unsigned *a_lo, unsigned *a_hi) {
-  if (H.pool_forb == nullptr || var < 0) return 0;
-  const cs_val d = row[var];
-  const long long width = (long long)d.hi - (long long)d.lo + 1;
-  const long long rel_lo = (long long)d.lo - (long long)H.root_lo[var];
-  if (width > 64 || rel_lo < 0 || rel_lo + width > 64) return 0;
-  cs_allowed_values(H.pool_forb[(size_t)row_index * n + var], (int)rel_lo, (int)width, a_lo, a_hi);
-  return 1;
-}
-
 /* S lanes (a whole wave, or a half or a quarter of one for small models) per parent: the open variable with
  * the smallest interval (ties: lowest index), the reference's "-o smallest-domain" idea (strategy.c:85-91) as a
  * pure function of the state.  Intervals wider than SPLIT_WIDTH are halved (two children) instead of enumerated.
- * -> var (-1: no open variable) and the number of children, in every lane of the segment */
+ * The same choice in every lane of the segment.  With n <= S every lane holds one variable: its interval, its
+ * set word and its root lower bound are loaded up front (independent, coalesced loads) and the chosen
+ * variable's are fetched from its lane -- no load depends on the outcome of the reduction. */
 template <int S>
-__device__ __forceinline__ void cs_branch_seg(const cs_val *__restrict__ row, int n, int sl, int *var, int *count) {
+__device__ __forceinline__ cs_choice cs_branch_seg(const cs_val *__restrict__ row, long long row_index, int n, int sl,
+                                                   const cs_holes &H) {
+  const bool one_each = n <= S;
   /* key = (width-1) * 2^32 + index, minimised over the segment */
   unsigned long long best = ~0ull;
-  for (int v = sl; v < n; v += S) {
-    const cs_val d = row[v];
-    if (d.lo != d.hi) {
-      const unsigned long long w = (unsigned long long)((long long)d.hi - (long long)d.lo);
-      const unsigned long long key = (w << 32) | (unsigned)v;
-      best = key < best ? key : best;
+  cs_val mine = cs_value(0);
+  unsigned long long my_forb = 0ull;
+  int my_root = 0;
+  if (one_each) {
+    if (sl < n) {
+      mine = row[sl];
+      if (H.pool_forb != nullptr) {
+        my_forb = H.pool_forb[(size_t)row_index * n + sl];
+        my_root = H.root_lo[sl];
+      }
+      if (mine.lo != mine.hi)
+        best = ((unsigned long long)((long long)mine.hi - (long long)mine.lo) << 32) | (unsigned)sl;
+    }
+  } else {
+    for (int v = sl; v < n; v += S) {
+      const cs_val d = row[v];
+      if (d.lo != d.hi) {
+        const unsigned long long w = (unsigned long long)((long long)d.hi - (long long)d.lo);
+        const unsigned long long key = (w << 32) | (unsigned)v;
+        best = key < best ? key : best;
+      }
     }
   }
   for (int o = S / 2; o > 0; o >>= 1) {
     const unsigned long long other = __shfl_xor(best, o);
     best = other < best ? other : best;
   }
-  if (best == ~0ull) {
-    *var = -1;
-    *count = 0;
+  cs_choice c;
+  c.var = -1; c.lo = 0; c.hi = 0; c.count = 0; c.a_lo = 0u; c.a_hi = 0u; c.holes = 0; c.skipped = 0;
+  if (best == ~0ull) return c;
+  const int var = (int)(best & 0xffffffffu);
+  cs_val d;
+  unsigned long long forb = 0ull;
+  int root = 0;
+  if (one_each) { /* from the lane that holds the variable (segment-relative source lane) */
+    d.lo = __shfl(mine.lo, var, S);
+    d.hi = __shfl(mine.hi, var, S);
+    if (H.pool_forb != nullptr) {
+      forb = ((unsigned long long)(unsigned)__shfl((int)(my_forb >> 32), var, S) << 32) |
+             (unsigned long long)(unsigned)__shfl((int)(unsigned)my_forb, var, S);
+      root = __shfl(my_root, var, S);
+    }
   } else {
-    const unsigned long long width = (best >> 32) + 1ull;
-    *var = (int)(best & 0xffffffffu);
-    *count = width > SPLIT_WIDTH ? 2 : (int)width;
+    d = row[var];
+    if (H.pool_forb != nullptr) {
+      forb = H.pool_forb[(size_t)row_index * n + var];
+      root = H.root_lo[var];
+    }
   }
+  const long long width = (long long)d.hi - (long long)d.lo + 1;
+  c.var = var;
+  c.lo = d.lo;
+  c.hi = d.hi;
+  c.count = width > SPLIT_WIDTH ? 2 : (int)width;
+  const long long rel_lo = (long long)d.lo - (long long)root;
+  if (H.pool_forb != nullptr && width <= 64 && rel_lo >= 0 && rel_lo + width <= 64) {
+    cs_allowed_values(forb, (int)rel_lo, (int)width, &c.a_lo, &c.a_hi);
+    const int allowed = __popc(c.a_lo) + __popc(c.a_hi);
+    c.holes = 1;
+    c.skipped = c.count - allowed;
+    c.count = allowed;
+  }
+  return c;
 }
 
 /* a workgroup takes SB / S consecutive parents; besides var and count per parent it leaves the number of
  * children of its parents in block_sum, so that the scan that follows runs over workgroups, not parents */
 template <int S>
 __global__ __launch_bounds__(SB) void cs_branch(const cs_val *__restrict__ pool, long long first_row, int parents,
-                                                int n, int *__restrict__ branch_var, int *__restrict__ child_count,
+                                                int n, cs_choice *__restrict__ choice,
                                                 int *__restrict__ block_sum, cs_holes H,
                                                 int *__restrict__ block_skip) {
   constexpr int PPB = SB / S;
@@ -159,22 +205,11 @@ __global__ __launch_bounds__(SB) void cs_branch(const cs_val *__restrict__ pool,
   const int seg = threadIdx.x / S, sl = threadIdx.x & (S - 1);
   const int p = blockIdx.x * PPB + seg;
   const int pc = p < parents ? p : parents - 1; /* segments past the end redo the last parent and drop it */
-  int var, count, skipped = 0;
-  const cs_val *row = pool + (size_t)(first_row + pc) * n;
-  cs_branch_seg<S>(row, n, sl, &var, &count);
-  unsigned a_lo, a_hi;
-  if (cs_row_holes(H, row, first_row + pc, n, var, &a_lo, &a_hi)) {
-    const int allowed = __popc(a_lo) + __popc(a_hi);
-    skipped = count - allowed;
-    count = allowed;
-  }
+  const cs_choice c = cs_branch_seg<S>(pool + (size_t)(first_row + pc) * n, first_row + pc, n, sl, H);
   if (sl == 0) {
-    if (p < parents) {
-      branch_var[p] = var;
-      child_count[p] = count;
-    }
-    s_cnt[seg] = p < parents ? count : 0;
-    s_skip[seg] = p < parents ? skipped : 0;
+    if (p < parents) choice[p] = c;
+    s_cnt[seg] = p < parents ? c.count : 0;
+    s_skip[seg] = p < parents ? c.skipped : 0;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -318,47 +353,48 @@ __global__ __launch_bounds__(1024) void cs_scan_classes(const int *__restrict__ 
   }
 }
 
-/* S lanes write the children {var, value, value, parent_row} of one parent at nodes[beg, beg + cnt) */
+/* S lanes write the children {var, value, value, parent_row} of one parent at nodes[beg, beg + c.count) */
 template <int S>
-__device__ __forceinline__ void cs_emit_seg(const cs_val *__restrict__ pool, long long row, int n, int var, int beg, int cnt,
-                                            csgpu_node *__restrict__ nodes, int low_values_last, unsigned scramble,
-                                            int sl, const cs_holes &H) {
+__device__ __forceinline__ void cs_emit_seg(const cs_choice &c, long long row, int beg, csgpu_node *__restrict__ nodes,
+                                            int low_values_last, unsigned scramble, int sl) {
+  const int var = c.var, cnt = c.count;
   if (var < 0) return;
-  const cs_val d = pool[(size_t)row * n + var];
-  const long long width = (long long)d.hi - (long long)d.lo + 1;
-  unsigned a_lo, a_hi;
-  if (cs_row_holes(H, pool + (size_t)row * n, row, n, var, &a_lo, &a_hi)) {
-    /* only the values the parent's set allows (cnt of them, as cs_branch counted): value lo + j is the r-th
-     * allowed one from below and takes the place the r-th value has in the full enumeration below */
-    unsigned h = 0u;
-    if (scramble != 0u && cnt > 0) {
-      h = (scramble ^ (unsigned)var * 2654435761u ^ (unsigned)row * 40503u);
-      h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
-      h %= (unsigned)cnt;
-    }
+  const long long width = (long long)c.hi - (long long)c.lo + 1;
+  unsigned h = 0u;
+  if (scramble != 0u && cnt > 0) {
+    /* ANY: the values are tried from a pseudo-random starting point (the reference randomises its
+     * value order too: the seed of step_val, csolve.c:284,331-338).  Deterministic: a function of
+     * the variable, the row and the iteration only. */
+    h = (scramble ^ (unsigned)var * 2654435761u ^ (unsigned)row * 40503u);
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    h %= (unsigned)cnt;
+  }
+  if (c.holes) {
+    /* only the values the parent's set allows (cnt of them): value lo + j is the r-th allowed one from below
+     * and takes the place the r-th value has in the full enumeration below */
     for (int j = sl; j < (int)width; j += S) {
-      const unsigned bit = j < 32 ? (a_lo >> j) & 1u : (a_hi >> (j - 32)) & 1u;
+      const unsigned bit = j < 32 ? (c.a_lo >> j) & 1u : (c.a_hi >> (j - 32)) & 1u;
       if (bit == 0u) continue;
-      const int r = j < 32 ? __popc(a_lo & ((1u << j) - 1u)) : __popc(a_lo) + __popc(a_hi & ((1u << (j - 32)) - 1u));
+      const int r = j < 32 ? __popc(c.a_lo & ((1u << j) - 1u)) : __popc(c.a_lo) + __popc(c.a_hi & ((1u << (j - 32)) - 1u));
       const int k = scramble != 0u ? (int)(((unsigned)r + (unsigned)cnt - h) % (unsigned)cnt) : (low_values_last ? cnt - 1 - r : r);
       csgpu_node nd;
       nd.var = var;
-      nd.lo = d.lo + j;
-      nd.hi = d.lo + j;
+      nd.lo = c.lo + j;
+      nd.hi = c.lo + j;
       nd.parent = (int)row;
       nodes[beg + k] = nd;
     }
     return;
   }
   if (width > SPLIT_WIDTH) { /* two halves, lower half first */
-    const int mid = (int)(((long long)d.lo + (long long)d.hi) >> 1);
+    const int mid = (int)(((long long)c.lo + (long long)c.hi) >> 1);
     if (sl < 2) {
       /* the pool is LIFO and later children land higher: the half written last is explored first */
       const int lower = low_values_last ? sl == 1 : sl == 0;
       csgpu_node nd;
       nd.var = var;
-      nd.lo = lower ? d.lo : mid + 1;
-      nd.hi = lower ? mid : d.hi;
+      nd.lo = lower ? c.lo : mid + 1;
+      nd.hi = lower ? mid : c.hi;
       nd.parent = (int)row;
       nodes[beg + sl] = nd;
     }
@@ -366,15 +402,8 @@ __device__ __forceinline__ void cs_emit_seg(const cs_val *__restrict__ pool, lon
   }
   for (int k = sl; k < cnt; k += S) {
     csgpu_node nd;
-    int value = low_values_last ? d.hi - k : d.lo + k;
-    if (scramble != 0u) {
-      /* ANY: the values are tried from a pseudo-random starting point (the reference randomises its
-       * value order too: the seed of step_val, csolve.c:284,331-338).  Deterministic: a function of
-       * the variable, the row and the iteration only. */
-      unsigned h = (scramble ^ (unsigned)var * 2654435761u ^ (unsigned)row * 40503u);
-      h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
-      value = d.lo + (int)(((unsigned)k + h) % (unsigned)cnt);
-    }
+    int value = low_values_last ? c.hi - k : c.lo + k;
+    if (scramble != 0u) value = c.lo + (int)(((unsigned)k + h) % (unsigned)cnt);
     nd.var = var;
     nd.lo = value;
     nd.hi = value;
@@ -386,20 +415,24 @@ __device__ __forceinline__ void cs_emit_seg(const cs_val *__restrict__ pool, lon
 /* same geometry as cs_branch<S>: block_off[b] = children before this workgroup's parents (the scan of
  * cs_branch's block sums), the few parents in front within the workgroup are added up directly */
 template <int S>
-__global__ __launch_bounds__(SB) void cs_emit(const cs_val *__restrict__ pool, long long first_row, int parents, int n,
-                                              const int *__restrict__ branch_var, const int *__restrict__ child_count,
+__global__ __launch_bounds__(SB) void cs_emit(long long first_row, int parents, const cs_choice *__restrict__ choice,
                                               const int *__restrict__ block_off, csgpu_node *__restrict__ nodes,
-                                              int low_values_last, unsigned scramble, cs_holes H) {
+                                              int low_values_last, unsigned scramble) {
   constexpr int PPB = SB / S;
-  __shared__ int s_cnt[PPB];
+  __shared__ cs_choice s_choice[PPB];
   const int seg = threadIdx.x / S, sl = threadIdx.x & (S - 1);
   const int p0 = blockIdx.x * PPB, p = p0 + seg;
-  if ((int)threadIdx.x < PPB) s_cnt[threadIdx.x] = p0 + (int)threadIdx.x < parents ? child_count[p0 + threadIdx.x] : 0;
+  if ((int)threadIdx.x < PPB) {
+    cs_choice c;
+    c.var = -1; c.lo = 0; c.hi = 0; c.count = 0; c.a_lo = 0u; c.a_hi = 0u; c.holes = 0; c.skipped = 0;
+    if (p0 + (int)threadIdx.x < parents) c = choice[p0 + threadIdx.x];
+    s_choice[threadIdx.x] = c;
+  }
   __syncthreads();
   if (p >= parents) return;
   int beg = block_off[blockIdx.x];
-  for (int j = 0; j < seg; j++) beg += s_cnt[j];
-  cs_emit_seg<S>(pool, first_row + p, n, branch_var[p], beg, s_cnt[seg], nodes, low_values_last, scramble, sl, H);
+  for (int j = 0; j < seg; j++) beg += s_choice[j].count;
+  cs_emit_seg<S>(s_choice[seg], first_row + p, beg, nodes, low_values_last, scramble, sl);
 }
 
 /* ---- small iterations (at most SMALL_PARENTS parents: always for ANY / MIN / MAX): one workgroup does what
@@ -410,27 +443,20 @@ __global__ __launch_bounds__(1024) void cs_expand_small(const cs_val *__restrict
                                                         int n, csgpu_node *__restrict__ nodes,
                                                         unsigned long long *__restrict__ counters, int low_values_last,
                                                         unsigned scramble, cs_holes H) {
-  __shared__ int s_var[SMALL_PARENTS], s_cnt[SMALL_PARENTS], s_off[SMALL_PARENTS], s_skip[SMALL_PARENTS];
+  __shared__ cs_choice s_choice[SMALL_PARENTS];
+  __shared__ int s_off[SMALL_PARENTS];
   __shared__ long long s_part[16];
   if (threadIdx.x < C_PER_ITERATION) counters[threadIdx.x] = 0ull;
   /* sixteen lanes per parent: all (at most 256) parents of the iteration in four passes of the workgroup */
   for (int p = (int)threadIdx.x >> 4; p < parents; p += 64) {
-    int var, count, skipped = 0;
-    const cs_val *row = pool + (size_t)(first_row + p) * n;
-    cs_branch_seg<16>(row, n, (int)threadIdx.x & 15, &var, &count);
-    unsigned a_lo, a_hi;
-    if (cs_row_holes(H, row, first_row + p, n, var, &a_lo, &a_hi)) {
-      const int allowed = __popc(a_lo) + __popc(a_hi);
-      skipped = count - allowed;
-      count = allowed;
-    }
-    if ((threadIdx.x & 15) == 0) { s_var[p] = var; s_cnt[p] = count; s_skip[p] = skipped; }
+    const cs_choice c = cs_branch_seg<16>(pool + (size_t)(first_row + p) * n, first_row + p, n, (int)threadIdx.x & 15, H);
+    if ((threadIdx.x & 15) == 0) s_choice[p] = c;
   }
   __syncthreads();
   long long total, skipped_total;
   const int t = (int)threadIdx.x;
-  (void)cs_block_excl_scan(t < parents ? (long long)s_skip[t] : 0, s_part, &skipped_total);
-  const long long ex = cs_block_excl_scan(t < parents ? (long long)s_cnt[t] : 0, s_part, &total);
+  (void)cs_block_excl_scan(t < parents ? (long long)s_choice[t].skipped : 0, s_part, &skipped_total);
+  const long long ex = cs_block_excl_scan(t < parents ? (long long)s_choice[t].count : 0, s_part, &total);
   if (t < parents) s_off[t] = (int)ex;
   if (t == 0) {
     counters[C_TOTAL_CHILDREN] = (unsigned long long)total;
@@ -438,8 +464,7 @@ __global__ __launch_bounds__(1024) void cs_expand_small(const cs_val *__restrict
   }
   __syncthreads();
   for (int p = (int)threadIdx.x >> 4; p < parents; p += 64)
-    cs_emit_seg<16>(pool, first_row + p, n, s_var[p], s_off[p], s_cnt[p], nodes, low_values_last, scramble,
-                    (int)threadIdx.x & 15, H);
+    cs_emit_seg<16>(s_choice[p], first_row + p, s_off[p], nodes, low_values_last, scramble, (int)threadIdx.x & 15);
 }
 
 
@@ -671,7 +696,8 @@ __global__ __launch_bounds__(1024) void cs_expand_burst(const cs_val *__restrict
                                                         const int *__restrict__ truth, int obj_var,
                                                         int32_t *__restrict__ solutions, long long max_solutions,
                                                         int32_t *__restrict__ best_solution) {
-  __shared__ int s_var[SMALL_PARENTS], s_cnt[SMALL_PARENTS], s_off[SMALL_PARENTS], s_skip[SMALL_PARENTS];
+  __shared__ cs_choice s_choice[SMALL_PARENTS];
+  __shared__ int s_off[SMALL_PARENTS];
   __shared__ long long s_part[16];
   __shared__ long long s_first, s_iter;
   __shared__ int s_parents;
@@ -712,22 +738,14 @@ __global__ __launch_bounds__(1024) void cs_expand_burst(const cs_val *__restrict
       objective == CS_OBJ_ANY ? (unsigned)((unsigned long long)s_iter * 2654435761ull + 0x9e3779b9u) | 1u : 0u;
   /* sixteen lanes per parent: all (at most 256) parents of the iteration in four passes of the workgroup */
   for (int p = (int)threadIdx.x >> 4; p < parents; p += 64) {
-    int var, count, skipped = 0;
-    const cs_val *row = pool + (size_t)(first_row + p) * n;
-    cs_branch_seg<16>(row, n, (int)threadIdx.x & 15, &var, &count);
-    unsigned a_lo, a_hi;
-    if (cs_row_holes(H, row, first_row + p, n, var, &a_lo, &a_hi)) {
-      const int allowed = __popc(a_lo) + __popc(a_hi);
-      skipped = count - allowed;
-      count = allowed;
-    }
-    if ((threadIdx.x & 15) == 0) { s_var[p] = var; s_cnt[p] = count; s_skip[p] = skipped; }
+    const cs_choice c = cs_branch_seg<16>(pool + (size_t)(first_row + p) * n, first_row + p, n, (int)threadIdx.x & 15, H);
+    if ((threadIdx.x & 15) == 0) s_choice[p] = c;
   }
   __syncthreads();
   long long total, skipped_total;
   const int t = (int)threadIdx.x;
-  (void)cs_block_excl_scan(t < parents ? (long long)s_skip[t] : 0, s_part, &skipped_total);
-  const long long ex = cs_block_excl_scan(t < parents ? (long long)s_cnt[t] : 0, s_part, &total);
+  (void)cs_block_excl_scan(t < parents ? (long long)s_choice[t].skipped : 0, s_part, &skipped_total);
+  const long long ex = cs_block_excl_scan(t < parents ? (long long)s_choice[t].count : 0, s_part, &total);
   if (t < parents) s_off[t] = (int)ex;
   if (t == 0) {
     counters[C_TOTAL_CHILDREN] = (unsigned long long)total;
@@ -740,8 +758,7 @@ __global__ __launch_bounds__(1024) void cs_expand_burst(const cs_val *__restrict
   }
   __syncthreads();
   for (int p = (int)threadIdx.x >> 4; p < parents; p += 64)
-    cs_emit_seg<16>(pool, first_row + p, n, s_var[p], s_off[p], s_cnt[p], nodes, low_values_last, scramble,
-                    (int)threadIdx.x & 15, H);
+    cs_emit_seg<16>(s_choice[p], first_row + p, s_off[p], nodes, low_values_last, scramble, (int)threadIdx.x & 15);
 }
 
 /* copy survivor k (child surv_list[k]) into pool row new_top + k: a workgroup takes cpb (at most SB) consecutive
@@ -879,7 +896,7 @@ __global__ __launch_bounds__(SB) void cs_move_rows(unsigned long long *__restric
 extern "C" void csgpu_search_free(csgpu_search *s) {
   if (s == NULL) return;
   (void)hipFree(s->pool_forb); (void)hipFree(s->d_child_forb); (void)hipFree(s->d_rebuild_nodes);
-  (void)hipFree(s->pool); (void)hipFree(s->d_branch_var); (void)hipFree(s->d_child_count); (void)hipFree(s->d_child_off); (void)hipFree(s->d_block_sum); (void)hipFree(s->d_block_skip);
+  (void)hipFree(s->pool); (void)hipFree(s->d_choice); (void)hipFree(s->d_child_off); (void)hipFree(s->d_block_sum); (void)hipFree(s->d_block_skip);
   (void)hipFree(s->d_nodes); (void)hipFree(s->d_child_states); (void)hipFree(s->d_complete_states);
   (void)hipFree(s->d_results); (void)hipFree(s->d_dest); (void)hipFree(s->d_complete_list); (void)hipFree(s->d_truth);
   (void)hipFree(s->d_block_surv); (void)hipFree(s->d_block_comp); (void)hipFree(s->d_surv_off); (void)hipFree(s->d_comp_off);
@@ -955,8 +972,7 @@ extern "C" int csgpu_search_create(const csgpu_model *m, int64_t pool_capacity, 
     ALLOC(s->d_rebuild_nodes, sizeof(csgpu_node) * (size_t)max_children);
   }
   /* up to max_children / 2 parents when every parent has two children */
-  ALLOC(s->d_branch_var, sizeof(int) * (size_t)max_children);
-  ALLOC(s->d_child_count, sizeof(int) * (size_t)max_children);
+  ALLOC(s->d_choice, sizeof(cs_choice) * (size_t)max_children);
   ALLOC(s->d_child_off, sizeof(int) * ((size_t)max_children + 1));
   ALLOC(s->d_block_sum, sizeof(int) * ((size_t)max_children + 1));
   ALLOC(s->d_block_skip, sizeof(int) * ((size_t)max_children + 1));
@@ -1200,14 +1216,14 @@ static int one_iteration(csgpu_search *s) {
       const int ppb = n <= 16 ? SB / 16 : (n <= 32 ? SB / 32 : SB / 64);
       pb = (unsigned)((parents + ppb - 1) / ppb);
       if (n <= 16)
-        hipLaunchKernelGGL(cs_branch<16>, dim3(pb), dim3(SB), 0, 0, s->pool, first_row, (int)parents, n, s->d_branch_var,
-                           s->d_child_count, s->d_block_sum, s->holes, s->d_block_skip);
+        hipLaunchKernelGGL(cs_branch<16>, dim3(pb), dim3(SB), 0, 0, s->pool, first_row, (int)parents, n, s->d_choice,
+                           s->d_block_sum, s->holes, s->d_block_skip);
       else if (n <= 32)
-        hipLaunchKernelGGL(cs_branch<32>, dim3(pb), dim3(SB), 0, 0, s->pool, first_row, (int)parents, n, s->d_branch_var,
-                           s->d_child_count, s->d_block_sum, s->holes, s->d_block_skip);
+        hipLaunchKernelGGL(cs_branch<32>, dim3(pb), dim3(SB), 0, 0, s->pool, first_row, (int)parents, n, s->d_choice,
+                           s->d_block_sum, s->holes, s->d_block_skip);
       else
-        hipLaunchKernelGGL(cs_branch<64>, dim3(pb), dim3(SB), 0, 0, s->pool, first_row, (int)parents, n, s->d_branch_var,
-                           s->d_child_count, s->d_block_sum, s->holes, s->d_block_skip);
+        hipLaunchKernelGGL(cs_branch<64>, dim3(pb), dim3(SB), 0, 0, s->pool, first_row, (int)parents, n, s->d_choice,
+                           s->d_block_sum, s->holes, s->d_block_skip);
       hipLaunchKernelGGL(cs_scan, dim3(1), dim3(1024), 0, 0, s->d_block_sum, (int)pb, s->d_child_off, s->d_counters,
                          (int)C_TOTAL_CHILDREN, (const int *)s->d_block_skip, (int)C_SKIPPED);
       /* first host read of the iteration: the number of children, and with it what the previous
@@ -1230,14 +1246,14 @@ static int one_iteration(csgpu_search *s) {
     d_children = NULL;
     if (children > s->max_children) return fail(CSGPU_E_LIMIT, "internal: more children than the batch buffers hold");
     if (n <= 16)
-      hipLaunchKernelGGL(cs_emit<16>, dim3(pb), dim3(SB), 0, 0, s->pool, first_row, (int)parents, n, s->d_branch_var,
-                         s->d_child_count, s->d_child_off, s->d_nodes, low_last, scramble, s->holes);
+      hipLaunchKernelGGL(cs_emit<16>, dim3(pb), dim3(SB), 0, 0, first_row, (int)parents, (const cs_choice *)s->d_choice,
+                         (const int *)s->d_child_off, s->d_nodes, low_last, scramble);
     else if (n <= 32)
-      hipLaunchKernelGGL(cs_emit<32>, dim3(pb), dim3(SB), 0, 0, s->pool, first_row, (int)parents, n, s->d_branch_var,
-                         s->d_child_count, s->d_child_off, s->d_nodes, low_last, scramble, s->holes);
+      hipLaunchKernelGGL(cs_emit<32>, dim3(pb), dim3(SB), 0, 0, first_row, (int)parents, (const cs_choice *)s->d_choice,
+                         (const int *)s->d_child_off, s->d_nodes, low_last, scramble);
     else
-      hipLaunchKernelGGL(cs_emit<64>, dim3(pb), dim3(SB), 0, 0, s->pool, first_row, (int)parents, n, s->d_branch_var,
-                         s->d_child_count, s->d_child_off, s->d_nodes, low_last, scramble, s->holes);
+      hipLaunchKernelGGL(cs_emit<64>, dim3(pb), dim3(SB), 0, 0, first_row, (int)parents, (const cs_choice *)s->d_choice,
+                         (const int *)s->d_child_off, s->d_nodes, low_last, scramble);
     /* the incumbent may just have improved */
     if (s->objective == CS_OBJ_MIN) obj_hi = cs_add(s->st.best, cs_neg(1));
     if (s->objective == CS_OBJ_MAX) obj_lo = cs_add(s->st.best, 1);

@@ -1010,9 +1010,26 @@ static int launch_eval_root(const csgpu_model *m, const csgpu_val *d_states, con
                             int64_t count, int32_t *d_truth, void *stream) {
   const size_t row = (size_t)m->host->n_vars * sizeof(cs_val);
   if (row * CS_WAVES_PER_BLOCK <= 64u * 1024u) {
-    hipLaunchKernelGGL(cs_eval_root_waves, dim3((unsigned)((count + CS_WAVES_PER_BLOCK - 1) / CS_WAVES_PER_BLOCK)),
-                       dim3(CS_BLOCK), row * CS_WAVES_PER_BLOCK, (hipStream_t)stream, m->tab, (const cs_val *)d_states, d_truth,
-                       (const int *)d_list, (const unsigned long long *)d_count, (long long)count);
+    /* grid-stride: enough workgroups to fill the machine, every wave keeps its share of the clause table */
+    int64_t blocks = (count + CS_WAVES_PER_BLOCK - 1) / CS_WAVES_PER_BLOCK;
+    if (blocks > (int64_t)m->n_cus * 16) blocks = (int64_t)m->n_cus * 16;
+    const int per = (m->img->n_clauses + CS_WAVE - 1) / CS_WAVE;
+#define CS_LAUNCH_EVAL_T(CPL, TREE)                                                                \
+  hipLaunchKernelGGL((cs_eval_root_waves<CPL, TREE>), dim3((unsigned)blocks), dim3(CS_BLOCK), row * CS_WAVES_PER_BLOCK, \
+                     (hipStream_t)stream, m->tab, (const cs_val *)d_states, d_truth, (const int *)d_list,                \
+                     (const unsigned long long *)d_count, (long long)count)
+#define CS_LAUNCH_EVAL(CPL)                                                                        \
+  do {                                                                                             \
+    if (m->img->n_trees > 0) CS_LAUNCH_EVAL_T(CPL, true);                                          \
+    else CS_LAUNCH_EVAL_T(CPL, false);                                                             \
+  } while (0)
+    if (per <= 1) CS_LAUNCH_EVAL(1);
+    else if (per <= 2) CS_LAUNCH_EVAL(2);
+    else if (per <= 4) CS_LAUNCH_EVAL(4);
+    else if (per <= 8) CS_LAUNCH_EVAL(8);
+    else CS_LAUNCH_EVAL(0);
+#undef CS_LAUNCH_EVAL
+#undef CS_LAUNCH_EVAL_T
   } else {
     hipLaunchKernelGGL(cs_eval_root, dim3((unsigned)count), dim3(CS_BLOCK), row + 16, (hipStream_t)stream, m->tab,
                        (const cs_val *)d_states, d_truth, (const int *)d_list, (const unsigned long long *)d_count);

@@ -1783,8 +1783,8 @@ __global__ __launch_bounds__(CS_BLOCK) void cs_propagate_sweeps(cs_tables T, con
 /* ---- three-valued evaluation of the root wide-and (eval.c:233-255) ---------------- */
 
 /* interval value of clause c on the domains `dom` (eval_<op> of the clause's root) */
-__device__ __forceinline__ cs_val cs_eval_clause(const cs_tables &T, int c, const cs_val *dom) {
-  const int4 rec = T.clause[c];
+template <bool HAS_TREE = true>
+__device__ __forceinline__ cs_val cs_eval_record(const cs_tables &T, const int4 rec, const cs_val *dom) {
   cs_val v = cs_value(1);
   if (rec.x == CS_CL_NE) {
     /* NOT(EQ(X_a, X_b + d)); no saturation possible on this path (cs_device.h) */
@@ -1801,7 +1801,7 @@ __device__ __forceinline__ cs_val cs_eval_clause(const cs_tables &T, int c, cons
       t[k] = cs_ev_lt_shifted(dom[l.x], dom[l.y], l.z);
     }
     v = cs_ev_or(t[0], t[1]);
-  } else if (rec.x == CS_CL_TREE) {
+  } else if (HAS_TREE && rec.x == CS_CL_TREE) { /* the interpreter's scratch costs 4.6 KB of private memory per lane */
     cs_tree_scratch S;
     const int base = T.tree_off[rec.y], len = T.tree_off[rec.y + 1] - base;
     cs_tree_eval(T, T.tnode + base, len, dom, S.val);
@@ -1810,8 +1810,15 @@ __device__ __forceinline__ cs_val cs_eval_clause(const cs_tables &T, int c, cons
   return v;
 }
 
-/* one WAVE per state (models whose domains fit a quarter of the LDS budget): no workgroup barrier, four states
- * per workgroup.  list / count_dev as below. */
+__device__ __forceinline__ cs_val cs_eval_clause(const cs_tables &T, int c, const cs_val *dom) {
+  return cs_eval_record<true>(T, T.clause[c], dom);
+}
+
+/* one WAVE per state at a time (models whose domains fit a quarter of the LDS budget): no workgroup barrier, four
+ * states per workgroup in flight, grid-stride over the states.  CPL > 0: the wave keeps its CPL clause records
+ * per lane in registers across its states (otherwise every state streams the clause table from L2 again: 27,000
+ * states x 5.7 KB on queens-16 were the whole cost of this kernel).  list / count_dev as below. */
+template <int CPL, bool HAS_TREE>
 __global__ __launch_bounds__(CS_BLOCK) void cs_eval_root_waves(cs_tables T, const cs_val *__restrict__ states,
                                                                int *__restrict__ truth, const int *__restrict__ list,
                                                                const unsigned long long *__restrict__ count_dev,
@@ -1820,20 +1827,41 @@ __global__ __launch_bounds__(CS_BLOCK) void cs_eval_root_waves(cs_tables T, cons
   const int n = T.n_vars;
   const int lane = threadIdx.x & (CS_WAVE - 1), wave_in_block = threadIdx.x >> 6;
   if (count_dev != nullptr && (long long)*count_dev < count) count = (long long)*count_dev;
-  const long long inst = (long long)blockIdx.x * CS_WAVES_PER_BLOCK + wave_in_block;
-  if (inst >= count) return;
+  if ((long long)blockIdx.x * CS_WAVES_PER_BLOCK >= count) return;
   cs_val *dom = (cs_val *)cs_lds + (size_t)wave_in_block * n;
-  const cs_val *src = states + (size_t)(list != nullptr ? list[inst] : inst) * n;
-  for (int v = lane; v < n; v += CS_WAVE) dom[v] = src[v];
-  cs_wave_sync();
-  int any_false = 0, any_open = 0;
-  for (int c = lane; c < T.n_clauses; c += CS_WAVE) {
-    const cs_val v = cs_eval_clause(T, c, dom);
-    any_false |= cs_is_false(v);
-    any_open |= !cs_is_false(v) && !cs_is_true(v);
+  constexpr int NR = CPL > 0 ? CPL : 1;
+  int4 rec[NR];
+  if (CPL > 0) {
+#pragma unroll
+    for (int q = 0; q < NR; q++) {
+      const int c = lane + q * CS_WAVE;
+      rec[q] = c < T.n_clauses ? T.clause[c] : make_int4(CS_CL_SKIP, 0, 0, 0);
+    }
   }
-  const bool f = __any(any_false), o = __any(any_open);
-  if (lane == 0) truth[inst] = f ? 0 : (o ? 2 : 1);
+  const long long waves_total = (long long)gridDim.x * CS_WAVES_PER_BLOCK;
+  for (long long inst = (long long)blockIdx.x * CS_WAVES_PER_BLOCK + wave_in_block; inst < count; inst += waves_total) {
+    const cs_val *src = states + (size_t)(list != nullptr ? list[inst] : inst) * n;
+    for (int v = lane; v < n; v += CS_WAVE) dom[v] = src[v];
+    cs_wave_sync();
+    int any_false = 0, any_open = 0;
+    if (CPL > 0) {
+#pragma unroll
+      for (int q = 0; q < NR; q++) {
+        const cs_val v = cs_eval_record<HAS_TREE>(T, rec[q], dom);
+        any_false |= cs_is_false(v);
+        any_open |= !cs_is_false(v) && !cs_is_true(v);
+      }
+    } else {
+      for (int c = lane; c < T.n_clauses; c += CS_WAVE) {
+        const cs_val v = cs_eval_record<HAS_TREE>(T, T.clause[c], dom);
+        any_false |= cs_is_false(v);
+        any_open |= !cs_is_false(v) && !cs_is_true(v);
+      }
+    }
+    const bool f = __any(any_false), o = __any(any_open);
+    if (lane == 0) truth[inst] = f ? 0 : (o ? 2 : 1);
+    cs_wave_sync();
+  }
 }
 
 /* list (nullable): instance i is row list[i] of states; count_dev (nullable): the number of instances, on the

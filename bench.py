@@ -45,17 +45,18 @@ from csolve_amd.solver import solve_root  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def measured_traffic(kernel_name, n_q, instances):
+def measured_traffic(kernel_name, workload_key, instances):
     """HBM bytes per launch from the committed PMC profile of this very kernel and workload
     (profiles/*_pmc_*.json, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in their own passes, FETCH_SIZE
-    doubled as MI355X_MICROARCH.md prescribes for gfx950), or None when there is no such profile."""
+    doubled as MI355X_MICROARCH.md prescribes for gfx950), or None when there is no such profile.
+    workload_key: "queens-64", "sudoku-25x25", ... (the first words of the profile's "workload")."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_*.json")), reverse=True):
         try:
             rec = json.load(open(path))
         except Exception:
             continue
-        if kernel_name in rec.get("kernel", "") and f"queens-{n_q} " in rec.get("workload", "") and \
+        if kernel_name in rec.get("kernel", "") and rec.get("workload", "").startswith(workload_key + " ") and \
                 f"{instances} instances" in rec.get("workload", "") and "hbm_traffic_bytes_per_launch" in rec:
             return rec["hbm_traffic_bytes_per_launch"]
     return None
@@ -465,7 +466,13 @@ def main():
     # (DESIGN.md 2/4): per node instance the state in and out (16 B x n), the forbidden sets in and
     # out when they are resident (16 B x n x FW), the 16-B node record and the 16-B result.
     # The clause tables are read once per workgroup from L2 and are not counted.
-    alg_bytes = ((0 if sets_only else 16 * n) + (16 * n * fw if use_sets else 0) + 16 + 16) * B
+    # An inconsistent node has no output row: only the register-resident kernel on models that fill its
+    # lanes (n = 64, 128, 256: straight-line stores) writes a (meaningless) row for it
+    # anyway, every other kernel stores the rows of consistent nodes only -- and only those are counted.
+    row_in = (0 if sets_only else 8 * n) + (8 * n * fw if use_sets else 0)
+    stores_all = kernel_name == "cs_propagate_ne_regs" and n in (64, 128, 256) and use_sets
+    stored = B if stores_all else int((res_h[:, 0] >= 0).sum())
+    alg_bytes = (row_in + 16 + 16) * B + row_in * stored
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
     # SURVEY 8(d) also prices every clause revision as 32 B of memory traffic (+ 8 B per narrowing);
     # in this design those bytes are LDS traffic, so that figure is reported separately
@@ -491,10 +498,11 @@ def main():
                    "inconsistent_fraction": fails_all / nodes_all,
                    "props_per_node": props_all / nodes_all, "revisions_per_node": revs_all / nodes_all},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None if (args.sudoku or args.schedule or sets_only) else measured_traffic(kernel_name, n_q, B),
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None if (args.schedule or sets_only) else measured_traffic(
+                         kernel_name, f"sudoku-{args.sudoku ** 2}x{args.sudoku ** 2}" if args.sudoku else f"queens-{n_q}", B),
                      "kernel": kernel_name, "kernel_ms": kernel_ms, "launch": "one hipGraph of the timed launches" if graph is not None else "launch loop",
                      "algorithmic_bytes_per_launch": alg_bytes,
-                     "bytes_per_node_instance": alg_bytes // B,
+                     "bytes_per_node_instance": alg_bytes // B, "output_rows_stored": stored,
                      "survey_8d_formula_gbps": survey_bytes / (kernel_ms * 1e-3) / 1e9},
     }
 

@@ -130,3 +130,40 @@ def schedule(tasks: int = 16, seed: int = 1, horizon_slack: int = 3) -> str:
     for t in range(tasks):
         lines.append(f"end >= t{t + 1}_end;")
     return "\n".join(lines) + "\n"
+
+
+def linear(n: int = 12, seed: int = 1, objective: str = "ANY") -> str:
+    """A seeded mixture of the clause shapes that take the direct bound-propagation paths: `x < y + d`,
+    `x <= y + d`, `x = y + d`, two-literal disjunctions of such literals, and a few `!=` (test workload for the
+    linear paths of the general kernel and for the clause-resident kernel; no reference example has this mix)."""
+    rng = LCG(seed * 104729 + n)
+    v = [f"L{i + 1}" for i in range(n)]
+    lines = [f"# linear mixture, {n} variables, seed {seed}", f"{objective};"]
+
+    def term(i, d):
+        return v[i] if d == 0 else f"{v[i]} {'+' if d > 0 else '-'} {abs(d)}"
+
+    for _ in range(2 * n):
+        a, b = rng.below(n), rng.below(n)
+        if a == b:
+            continue
+        d = rng.below(13) - 6
+        kind = rng.below(10)
+        if kind < 4:
+            lines.append(f"{v[a]} < {term(b, d + 8)};")
+        elif kind < 6:
+            lines.append(f"{v[a]} <= {term(b, d + 6)};")
+        elif kind < 7:
+            lines.append(f"{v[a]} != {term(b, d)};")
+        else:
+            c, e = rng.below(n), rng.below(n)
+            if c == e:
+                continue
+            lines.append(f"{v[a]} > {term(b, d)} | {v[c]} > {term(e, rng.below(9) - 4)};")
+    # one equality chain so that EQ clauses are present without making the model infeasible
+    for i in range(0, n - 1, 5):
+        lines.append(f"{v[i + 1]} = {term(i, 1 + rng.below(3))};")
+    for i in range(n):
+        lo = rng.below(7) - 3
+        lines.append(f"{lo} <= {v[i]}; {v[i]} <= {lo + 20 + rng.below(20)};")
+    return "\n".join(lines) + "\n"

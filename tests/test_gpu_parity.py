@@ -493,3 +493,52 @@ def test_all_kernels_agree_on_irregular_networks():
             assert torch.equal(r[ok][:, :2], r1[ok][:, :2]), (seed, n, values, k)
             seen.add(k)
     assert seen == {2, 3, 4, 5, 6}
+
+
+def test_linear_mixtures_through_both_general_kernels_and_the_oracle():
+    """Seeded mixtures of <, <=, =, != and two-literal disjunctions (csolve_amd.problems.linear): the event-driven
+    kernel, the clause-resident kernel and the tree interpreter (linear fast paths off) give the same verdicts
+    and fixpoints on multi-level random batches, and a sample equals the oracle's."""
+    import bench
+    from csolve_amd import problems
+    from csolve_amd.solver import set_linear_fast_paths, solve_root
+    from oracle.cs_oracle import Model as OModel, Oracle
+    checked = 0
+    for seed in range(1, 13):
+        text = problems.linear(6 + 3 * seed, seed)
+        try:
+            model = solve_root(text)
+        except Exception:
+            continue  # inconsistent at the root
+        assert model.qualifies(6)
+        states_in, nodes, _ = bench.make_instances(model, 2048, seed=seed, walks=256)
+        outs = {}
+        for k in (1, 6):
+            model.set_kernel(k)
+            o, r = model.propagate(states_in, nodes)
+            torch.cuda.synchronize()
+            outs[k] = (o, r)
+        try:
+            set_linear_fast_paths(False)
+            slow = solve_root(text)
+        finally:
+            set_linear_fast_paths(True)
+        slow.set_kernel(1)
+        outs["tree"] = slow.propagate(states_in, nodes)
+        torch.cuda.synchronize()
+        ok = outs[1][1][:, 0] >= 0
+        for k in (6, "tree"):
+            assert torch.equal(outs[k][1][:, 0] >= 0, ok), (seed, k)
+            assert torch.equal(outs[k][0][ok], outs[1][0][ok]), (seed, k)
+        om = OModel.parse(text)
+        om.set_domains(model.domains())
+        om.index()
+        orc = Oracle(om)
+        st_h, nd_h = states_in.cpu().numpy(), nodes.cpu().numpy()
+        sample = np.arange(0, 2048, 16)
+        st, exp = orc.instances(st_h[nd_h[sample, 3]], nd_h[sample, 0], nd_h[sample, 1])
+        assert ((st < 0) == ~ok.cpu().numpy()[sample]).all(), seed
+        good = sample[st >= 0]
+        assert (outs[6][0].cpu().numpy()[good] == exp[st >= 0]).all(), seed
+        checked += 1
+    assert checked >= 6

@@ -64,13 +64,16 @@ def test_optimisation_reaches_the_reference_optimum(name, best):
     assert int(truth[0]) == 1
 
 
-def test_search_counters_match_oracle_tree_on_all():
+@pytest.mark.parametrize("which", ["queens7", "offsets6x5", "offsets5x9"])
+def test_search_counters_match_oracle_tree_on_all(which):
     """For ALL the set of explored nodes does not depend on the walking order as long as the
     branching variable of a state is a function of the state: compare CALLS/CUTS/solutions with a
-    plain CPU walk of the same tree that uses the oracle for every child."""
+    plain CPU walk of the same tree that uses the oracle for every child (the engine counts the children
+    that a parent's own forbidden set rules out without launching them; the walk propagates every one)."""
     from csolve_amd import problems
     from oracle.cs_oracle import Model as OModel, Oracle
-    text = problems.queens(7, "ALL")
+    text = {"queens7": lambda: problems.queens(7, "ALL"), "offsets6x5": lambda: problems.offsets(6, 5, 2, "ALL"),
+            "offsets5x9": lambda: problems.offsets(5, 9, 4, "ALL")}[which]()
     model, s, st = _solve(text)
     om = OModel.parse(text)
     om.set_domains(model.domains())

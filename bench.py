@@ -374,7 +374,8 @@ def main():
         if forced in (0, 5) and model.qualifies(5) and args.layout == "intervals":
             kernel_name = "cs_propagate_ne_packed"
     else:
-        kernel_name = {1: "cs_propagate_events", 2: "cs_propagate_ne_lds", 6: "cs_propagate_clause_rounds"}[model.kernel()]
+        kernel_name = {1: "cs_propagate_events", 2: "cs_propagate_ne_lds", 3: "cs_propagate_ne_bitset", 4: "cs_propagate_ne_regs",
+                       5: "cs_propagate_ne_packed", 6: "cs_propagate_clause_rounds"}[model.kernel()]
     n = model.n_vars
     info = model.device_info()
 

@@ -30,9 +30,9 @@ def _text(kind, size):
 
 
 def _kernels(model):
-    """every kernel that can run this model: 1 = general, 2 = LDS-resident (when it qualifies)"""
+    """every kernel that can run this model"""
     ks = [1]
-    if model.kernel() == 2:
+    if model.qualifies(2):
         ks.append(2)
     if model.forbidden_words() > 0:
         ks.append(3)  # forbidden-set kernel, sets rebuilt from the incoming state
@@ -63,7 +63,7 @@ def test_reference_walks_on_reference_model(name):
     walk = read_walk(golden("walks", name + ".walk.gz"))
     model = Model.from_dump(golden("models", name + ".model")).finalize()
     if name in NE_ONLY:
-        assert model.kernel() == 2, "pure != networks of this size must take the LDS-resident kernel"
+        assert model.kernel() in (3, 4, 5), "pure != networks of this size must take a forbidden-set kernel"
     for k in _kernels(model):
         model.set_kernel(k)
         out, res = _gpu_walk(model, walk)

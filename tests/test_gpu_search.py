@@ -257,3 +257,35 @@ def test_children_cut_by_their_parents_set_are_counted_not_launched(monkeypatch)
             assert len(set(row)) == n and len(set(row + np.arange(n))) == n and len(set(row - np.arange(n))) == n
         if objective == "ALL":
             assert runs[0] == runs[1]
+
+
+def test_lanes_on_one_gpu_reach_the_same_results():
+    """LaneSearch: several engines of one model on one GPU, a host thread each, exchanging incumbent and open
+    states like ranks do.  ALL: the same tree (nodes, cuts, solutions) as one engine; MIN: the same optimum with a
+    valid solution on the lane that holds it; reproducible run to run."""
+    from csolve_amd import problems
+    from csolve_amd.parallel import LaneSearch
+    from csolve_amd.solver import Search, solve_root
+    model = solve_root(problems.queens(10, "ALL"))
+    one = Search(model, 1 << 18, 1 << 14)
+    one.put(model.root_state())
+    ref = one.run()
+    runs = []
+    for _ in range(2):
+        lanes = [Search(model, 1 << 18, 1 << 14) for _ in range(3)]
+        tot = LaneSearch(lanes, model.objective, slice_iterations=4, seed_states_per_lane=16, low_water=16).run(model.root_state())
+        runs.append(tot)
+        assert tot["done"] == 1
+        assert (tot["nodes"], tot["cuts"], tot["solutions"]) == (ref["nodes"], ref["cuts"], ref["solutions"])
+        assert all(x > 0 for x in tot["lanes"])
+    assert runs[0] == runs[1]
+    model = solve_root(problems.schedule(8, 1))
+    runs = []
+    for _ in range(2):
+        lanes = [Search(model, 1 << 18, 1 << 14) for _ in range(4)]
+        tot = LaneSearch(lanes, model.objective).run(model.root_state())
+        assert tot["done"] == 1 and tot["best"] == 31
+        rows = [e.best_solution() for e in lanes]
+        assert any(r is not None and r[model.objective_var] == 31 for r in rows)
+        runs.append(tot)
+    assert runs[0] == runs[1]

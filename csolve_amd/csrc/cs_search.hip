@@ -80,7 +80,8 @@ struct csgpu_search {
   int64_t seed_count, seed_cap, restart_base, since_restart;
   uint64_t luby_threshold, luby_counter;
   /* device-driven iterations (ANY / MIN / MAX): BURST_ITERATIONS iterations per host round trip, as one hipGraph */
-  unsigned long long *d_burst, *h_burst; /* [B_COUNT] device / pinned host; h_burst[B_COUNT ...] = copy of the counters */
+  unsigned long long *d_burst, *h_burst; /* [B_COUNT] device / pinned host; h_burst[B_COUNT ...] = copy of the counters,
+                                          * then the incumbent */
   hipStream_t burst_stream;
   hipGraphExec_t burst_exec;
   int64_t burst_limit; /* parents per iteration the graph was built for (0: none) */
@@ -92,6 +93,7 @@ struct csgpu_search {
 extern "C" int csgpu_internal_set_error(int code, const char *msg); /* cs_capi.hip */
 static int fail(int code, const char *msg) { return csgpu_internal_set_error(code, msg); }
 static int flush_accept_results(csgpu_search *s);
+static int burst_applicable(const csgpu_search *s);
 
 #define SPLIT_WIDTH 256 /* wider intervals are halved instead of enumerated (csolve.c:121-150 style) */
 #define HIP_OK(expr)                                                           \
@@ -594,7 +596,8 @@ __device__ __forceinline__ void cs_accept_block(const cs_val *__restrict__ child
                                                 const int *__restrict__ truth, int n, int objective, int obj_var,
                                                 unsigned long long *__restrict__ counters,
                                                 unsigned long long *__restrict__ burst, int32_t *__restrict__ solutions,
-                                                long long max_solutions, int32_t *__restrict__ best_solution) {
+                                                long long max_solutions, int32_t *__restrict__ best_solution,
+                                                int *__restrict__ best /* the incumbent: may be shared between engines */) {
   __shared__ long long s_key[256];
   __shared__ int s_cnt[256];
   __shared__ int s_pick;
@@ -653,9 +656,9 @@ __device__ __forceinline__ void cs_accept_block(const cs_val *__restrict__ child
         if (opt) {
           const long long v = (best_key - (long long)idx) / 4294967296ll;
           const int val = objective == CS_OBJ_MIN ? (int)v : (int)-v;
-          int *best = (int *)&counters[C_BEST];
-          if (objective == CS_OBJ_MIN ? val < *best : val > *best) {
-            *best = val;
+          /* atomic: engines that share the incumbent accept concurrently */
+          const int old = objective == CS_OBJ_MIN ? atomicMin(best, val) : atomicMax(best, val);
+          if (objective == CS_OBJ_MIN ? val < old : val > old) {
             burst[B_IMPROVED] = 1ull;
             s_pick = idx;
           }
@@ -678,8 +681,9 @@ __global__ __launch_bounds__(256) void cs_accept_burst(const cs_val *__restrict_
                                                        unsigned long long *__restrict__ counters,
                                                        unsigned long long *__restrict__ burst,
                                                        int32_t *__restrict__ solutions, long long max_solutions,
-                                                       int32_t *__restrict__ best_solution) {
-  cs_accept_block(child_states, list, truth, n, objective, obj_var, counters, burst, solutions, max_solutions, best_solution);
+                                                       int32_t *__restrict__ best_solution, int *__restrict__ best) {
+  cs_accept_block(child_states, list, truth, n, objective, obj_var, counters, burst, solutions, max_solutions, best_solution,
+                  best);
   if (threadIdx.x == 0) counters[C_COMPLETE] = 0ull; /* accepted: the next burst's first expansion must not do it again */
 }
 
@@ -695,7 +699,7 @@ __global__ __launch_bounds__(1024) void cs_expand_burst(const cs_val *__restrict
                                                         const int *__restrict__ complete_list,
                                                         const int *__restrict__ truth, int obj_var,
                                                         int32_t *__restrict__ solutions, long long max_solutions,
-                                                        int32_t *__restrict__ best_solution) {
+                                                        int32_t *__restrict__ best_solution, int *__restrict__ best) {
   __shared__ cs_choice s_choice[SMALL_PARENTS];
   __shared__ int s_off[SMALL_PARENTS];
   __shared__ long long s_part[16];
@@ -704,7 +708,7 @@ __global__ __launch_bounds__(1024) void cs_expand_burst(const cs_val *__restrict
   /* first the accept of the previous iteration's complete children (their root evaluation has run): it decides
    * whether ANY is done and moves the incumbent this iteration's fixpoints will see */
   cs_accept_block(child_states, complete_list, truth, n, objective, obj_var, counters, burst, solutions, max_solutions,
-                  best_solution);
+                  best_solution, best);
   if (threadIdx.x == 0) {
     const long long top = (long long)burst[B_TOP];
     /* a few parents while the pool is small (dive for a solution / an incumbent first), more once there is a
@@ -1007,7 +1011,7 @@ extern "C" int csgpu_search_create(const csgpu_model *m, int64_t pool_capacity, 
     if (s->fw == 1 && s->holes.root_lo != NULL && !(e != NULL && e[0] == '0')) s->holes.pool_forb = s->pool_forb;
   }
   HIP_OK(hipMalloc((void **)&s->d_burst, sizeof(unsigned long long) * B_COUNT));
-  HIP_OK(hipHostMalloc((void **)&s->h_burst, sizeof(unsigned long long) * (B_COUNT + C_COUNT), 0));
+  HIP_OK(hipHostMalloc((void **)&s->h_burst, sizeof(unsigned long long) * (B_COUNT + C_COUNT + 1), 0));
   HIP_OK(hipStreamCreate(&s->burst_stream));
   {
     const char *e = getenv("CSGPU_SEARCH_BURST");
@@ -1132,6 +1136,29 @@ extern "C" int csgpu_search_set_best(csgpu_search *s, int32_t best) {
   if (better) {
     s->st.best = best;
     HIP_OK(hipMemcpy(s->d_best, &best, sizeof(int), hipMemcpyHostToDevice));
+  }
+  return CSGPU_OK;
+}
+
+extern "C" int csgpu_search_share_incumbent(csgpu_search *s, csgpu_search *with) {
+  if (s == NULL || with == NULL || s->objective != with->objective || s->obj_var != with->obj_var)
+    return fail(CSGPU_E_ARG, "bad argument");
+  if (s->objective != CS_OBJ_MIN && s->objective != CS_OBJ_MAX) return CSGPU_OK; /* nothing to share */
+  if (!burst_applicable(s) || !burst_applicable(with))
+    return fail(CSGPU_E_STATE, "a shared incumbent needs the device-driven iterations");
+  const int rcf = flush_accept_results(s);
+  if (rcf != CSGPU_OK) return rcf;
+  /* the better of the two goes into the shared word */
+  int mine = 0, theirs = 0;
+  HIP_OK(hipMemcpy(&mine, s->d_best, sizeof(int), hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(&theirs, with->d_best, sizeof(int), hipMemcpyDeviceToHost));
+  const int best = s->objective == CS_OBJ_MIN ? (mine < theirs ? mine : theirs) : (mine > theirs ? mine : theirs);
+  HIP_OK(hipMemcpy(with->d_best, &best, sizeof(int), hipMemcpyHostToDevice));
+  s->d_best = with->d_best;
+  s->st.best = best;
+  if (s->burst_exec != NULL) { /* the graph holds the old pointer */
+    (void)hipGraphExecDestroy(s->burst_exec);
+    s->burst_exec = NULL;
   }
   return CSGPU_OK;
 }
@@ -1371,7 +1398,7 @@ static int enqueue_burst(csgpu_search *s, hipStream_t st) {
     hipLaunchKernelGGL(cs_expand_burst, dim3(1), dim3(1024), 0, st, s->pool, n, s->d_nodes, s->d_counters, s->d_burst,
                        s->objective, (long long)s->max_width, (long long)s->cap, room_limit, s->holes,
                        (const cs_val *)s->d_child_states, (const int *)s->d_complete_list, (const int *)s->d_truth,
-                       s->obj_var, s->d_solutions, (long long)s->max_solutions, s->d_best_solution);
+                       s->obj_var, s->d_solutions, (long long)s->max_solutions, s->d_best_solution, s->d_best);
     int rc;
     if (s->fw > 0)
       rc = csgpu_internal_propagate_fb(s->m, (const csgpu_val *)s->pool, (const uint64_t *)s->pool_forb, s->d_nodes,
@@ -1394,7 +1421,7 @@ static int enqueue_burst(csgpu_search *s, hipStream_t st) {
   /* the last iteration's accept (the others ran at the head of the following expansion) */
   hipLaunchKernelGGL(cs_accept_burst, dim3(1), dim3(256), 0, st, s->d_child_states, s->d_complete_list, s->d_truth, n,
                      s->objective, s->obj_var, s->d_counters, s->d_burst, s->d_solutions, (long long)s->max_solutions,
-                     s->d_best_solution);
+                     s->d_best_solution, s->d_best);
   HIP_OK(hipGetLastError());
   return CSGPU_OK;
 }
@@ -1441,6 +1468,7 @@ static int run_burst(csgpu_search *s, int64_t budget, int64_t *done) {
   HIP_OK(hipMemcpyAsync(h, s->d_burst, sizeof(unsigned long long) * B_COUNT, hipMemcpyDeviceToHost, s->burst_stream));
   HIP_OK(hipMemcpyAsync(h + B_COUNT, s->d_counters, sizeof(unsigned long long) * C_COUNT, hipMemcpyDeviceToHost,
                         s->burst_stream));
+  HIP_OK(hipMemcpyAsync(h + B_COUNT + C_COUNT, s->d_best, sizeof(int), hipMemcpyDeviceToHost, s->burst_stream));
   HIP_OK(hipStreamSynchronize(s->burst_stream));
   if (getenv("CSGPU_SEARCH_TRACE") != NULL)
     fprintf(stderr, "burst: iters %llu top %llu nodes %llu cuts %llu | surv %llu complete %llu children %llu solutions %llu stored %llu best %d\n",
@@ -1456,7 +1484,7 @@ static int run_burst(csgpu_search *s, int64_t budget, int64_t *done) {
   s->st.props += h[B_PROPS];
   s->st.revisions += h[B_REVS];
   s->st.solutions = h[B_COUNT + C_SOLUTIONS];
-  if (s->objective == CS_OBJ_MIN || s->objective == CS_OBJ_MAX) s->st.best = (int)(unsigned)h[B_COUNT + C_BEST];
+  if (s->objective == CS_OBJ_MIN || s->objective == CS_OBJ_MAX) s->st.best = *(const int *)(h + B_COUNT + C_COUNT);
   if (h[B_IMPROVED] != 0ull) s->have_best_solution = 1;
   return CSGPU_OK;
 }

@@ -190,6 +190,9 @@ class LaneSearch:
         from concurrent.futures import ThreadPoolExecutor
         lanes = self.engines
         first = lanes[0]
+        if self.objective in (OBJ_MIN, OBJ_MAX) and hasattr(first, "share_incumbent"):
+            for lane in lanes[1:]:
+                lane.share_incumbent(first)  # one word of device memory: a better solution bounds every lane at once
         first.put(root_state)
         stats = [first.run(0)] + [None] * (len(lanes) - 1)
         if len(lanes) > 1:

@@ -305,6 +305,11 @@ class Search:
     def set_restart(self, iterations: int):
         check(load_library().csgpu_search_set_restart(self._h, int(iterations)))
 
+    def share_incumbent(self, other: "Search"):
+        """keep the incumbent in `other`'s word of device memory (MIN / MAX engines of one model on one device)"""
+        check(load_library().csgpu_search_share_incumbent(self._h, other._h))
+        self._shares = other  # keeps the owner of the word alive
+
     def set_best(self, best: int):
         check(load_library().csgpu_search_set_best(self._h, int(best)))
 

@@ -255,6 +255,11 @@ int csgpu_search_set_parents(csgpu_search *s, int64_t parents_per_iteration);
 int csgpu_search_set_restart(csgpu_search *s, int64_t iterations);
 /* merge an incumbent found elsewhere (objective_best of the shared page, objective.c:89-93) */
 int csgpu_search_set_best(csgpu_search *s, int32_t best);
+/* MIN / MAX engines of the same model on one device: from now on `s` keeps its incumbent in `with`'s word of
+ * device memory (the analogue of the reference's shared page, csolve.c:86-97): what one engine accepts bounds
+ * the very next fixpoints of the other.  `with` must outlive `s`; csgpu_search_reset of either resets the word.
+ * Needs the device-driven iterations (CSGPU_E_STATE otherwise); a no-op for ANY / ALL. */
+int csgpu_search_share_incumbent(csgpu_search *s, csgpu_search *with);
 /* run up to max_iterations iterations (stops early when done).  ANY/MIN/MAX iterations are enqueued
  * sixteen at a time as one hipGraph with the bookkeeping between them on the device (pool top, child
  * counts, incumbent, stop conditions); the host reads the totals once per sixteen.  Environment, read

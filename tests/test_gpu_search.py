@@ -261,8 +261,8 @@ def test_children_cut_by_their_parents_set_are_counted_not_launched(monkeypatch)
 
 def test_lanes_on_one_gpu_reach_the_same_results():
     """LaneSearch: several engines of one model on one GPU, a host thread each, exchanging incumbent and open
-    states like ranks do.  ALL: the same tree (nodes, cuts, solutions) as one engine; MIN: the same optimum with a
-    valid solution on the lane that holds it; reproducible run to run."""
+    states like ranks do.  ALL: the same tree (nodes, cuts, solutions) as one engine, reproducible run to run; MIN:
+    the same optimum, with a solution that attains it on the lane that found it."""
     from csolve_amd import problems
     from csolve_amd.parallel import LaneSearch
     from csolve_amd.solver import Search, solve_root
@@ -279,13 +279,12 @@ def test_lanes_on_one_gpu_reach_the_same_results():
         assert (tot["nodes"], tot["cuts"], tot["solutions"]) == (ref["nodes"], ref["cuts"], ref["solutions"])
         assert all(x > 0 for x in tot["lanes"])
     assert runs[0] == runs[1]
+    # MIN: the lanes keep ONE incumbent in device memory (share_incumbent), so what a lane prunes depends on when
+    # the others find their solutions: the optimum is fixed, the node counts are not
     model = solve_root(problems.schedule(8, 1))
-    runs = []
     for _ in range(2):
         lanes = [Search(model, 1 << 18, 1 << 14) for _ in range(4)]
         tot = LaneSearch(lanes, model.objective).run(model.root_state())
         assert tot["done"] == 1 and tot["best"] == 31
         rows = [e.best_solution() for e in lanes]
         assert any(r is not None and r[model.objective_var] == 31 for r in rows)
-        runs.append(tot)
-    assert runs[0] == runs[1]

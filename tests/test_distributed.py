@@ -94,3 +94,40 @@ def test_sharded_minimisation_shares_the_incumbent():
     """schedule-6 MIN over 2 ranks: optimum 22 (reference golden), known to every rank."""
     res = _run(2, open(golden("problems", "schedule6_s1.txt")).read())
     assert all(r[5] == 22 for r in res)
+
+
+def _oracle_engine(text):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from cpu_engine import OracleEngine
+    from oracle.cs_oracle import Model as OModel, Oracle
+    om = OModel.parse(text)
+    o0 = Oracle(om)
+    o0.set_root_phase(True)
+    assert o0.propagate(om.root, om.n_vars) >= 0
+    om.set_domains(o0.domains())
+    om.index()
+    return om, OracleEngine(om)
+
+
+def test_lanes_in_one_process():
+    """LaneSearch (several engines in one process, a host thread each, the exchange of ShardedSearch without
+    collectives) over the oracle-backed CPU engines: queens-7 ALL walks the single-engine tree with every lane
+    taking part; schedule-6 MIN reaches 22."""
+    from csolve_amd import problems
+    from csolve_amd.parallel import LaneSearch
+    text = problems.queens(7, "ALL")
+    om, single = _oracle_engine(text)
+    root = torch.from_numpy(om.domains()).unsqueeze(0).contiguous()
+    single.put(root)
+    ref = single.run(1 << 30)
+    assert ref["solutions"] == 40
+    lanes = [_oracle_engine(text)[1] for _ in range(3)]
+    tot = LaneSearch(lanes, om.view.objective, slice_iterations=4, seed_states_per_lane=4, low_water=4).run(root)
+    assert tot["done"] == 1 and (tot["nodes"], tot["cuts"], tot["solutions"]) == (ref["nodes"], ref["cuts"], 40)
+    assert all(x > 0 for x in tot["lanes"])
+    text = open(golden("problems", "schedule6_s1.txt")).read()
+    om, _ = _oracle_engine(text)
+    root = torch.from_numpy(om.domains()).unsqueeze(0).contiguous()
+    lanes = [_oracle_engine(text)[1] for _ in range(2)]
+    tot = LaneSearch(lanes, om.view.objective, slice_iterations=8, seed_states_per_lane=4, low_water=4).run(root)
+    assert tot["done"] == 1 and tot["best"] == 22

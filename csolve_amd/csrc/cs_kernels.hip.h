@@ -1172,10 +1172,11 @@ __device__ __forceinline__ int cs_wave_sum(int x) {
  * instead of branching around it.
  *
  * No variable 64-bit shifts: the sets are handled as 32-bit words (two per u64).  A first version built
- * the bit with `1ull << bit` (v_lshlrev_b64) and, with more than one wave per SIMD, produced wrong bits
- * in a timing-dependent 1-15 % of the nodes of large batches; the same loop with 32-bit shifts, or with
- * the consumers of the shift moved a few instructions away, is exact (DESIGN.md 3.4 has the
- * experiments).  tools/validate_k4.py and the large-batch GPU test guard this kernel. */
+ * the bit with `1ull << bit`; the compiler put the shift amount into the last vector register the kernel
+ * owns (`v_lshlrev_b64 v[44:45], v47, 1` with 48 registers), and on gfx950 a 64-bit shift whose amount is
+ * in the last register of the wave's allocation intermittently shifts by v0 instead when several waves
+ * share a SIMD (tools/k4_fault_repro.md, tools/shift64_last_vgpr.hip).  tools/check_isa_shift64.py
+ * (tests/test_isa_lint.py) fails the CPU suite if any kernel of the library ever gets such a shift. */
 /* 32-bit words of a forbidden set, word q = values 32 q .. 32 q + 31 relative to the variable's root lower bound:
  * lowest and highest allowed value within [from, to] (first > last: none) */
 template <int NW>

@@ -375,7 +375,7 @@ def main():
             kernel_name = "cs_propagate_ne_packed"
     else:
         kernel_name = {1: "cs_propagate_events", 2: "cs_propagate_ne_lds", 3: "cs_propagate_ne_bitset", 4: "cs_propagate_ne_regs",
-                       5: "cs_propagate_ne_packed", 6: "cs_propagate_clause_rounds"}[model.kernel()]
+                       5: "cs_propagate_ne_packed", 6: "cs_propagate_clause_rounds", 7: "cs_propagate_ne_shave"}[model.kernel()]
     n = model.n_vars
     info = model.device_info()
 
@@ -471,7 +471,8 @@ def main():
     # lanes (n = 64, 128, 256: straight-line stores) writes a (meaningless) row for it
     # anyway, every other kernel stores the rows of consistent nodes only -- and only those are counted.
     row_in = (0 if sets_only else 8 * n) + (8 * n * fw if use_sets else 0)
-    stores_all = kernel_name == "cs_propagate_ne_regs" and n in (64, 128, 256) and use_sets
+    stores_all = (kernel_name == "cs_propagate_ne_regs" and n in (64, 128, 256) and use_sets) or \
+                 (kernel_name == "cs_propagate_ne_shave" and n in (64, 128, 256))
     stored = B if stores_all else int((res_h[:, 0] >= 0).sum())
     alg_bytes = (row_in + 16 + 16) * B + row_in * stored
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9

@@ -11,6 +11,7 @@
 
 #include "../../include/csolve_gpu.h"
 #include "cs_kernels.hip.h"
+#include "cs_shave.hip.h"
 #include "cs_internal.h"
 
 static thread_local char g_err[512] = "";
@@ -441,6 +442,34 @@ static const void *ne_regs_kernel(int width, int fw, int n_vars, int fast, int s
 #undef CS_PICK_D
 }
 
+/* kernel 7 (cs_shave.hip.h): interval states only; entry width, variables per lane, slots per pair known at
+ * compile time when 1 or 3, FULL when the variables fill the lanes */
+static const void *ne_shave_kernel(int width, int n_vars, int slots, int full) {
+  const int chunks = (n_vars + CS_WAVE - 1) / CS_WAVE;
+  const int r = chunks <= 1 ? 1 : (chunks <= 2 ? 2 : 4);
+  const int sl = slots == 1 ? 1 : (slots == 3 ? 3 : 0);
+#define CS_PICK_F(E, RR, DD, SS)                                                                   \
+  return full ? (const void *)cs_propagate_ne_shave<E, RR, DD, SS, true>                            \
+              : (const void *)cs_propagate_ne_shave<E, RR, DD, SS, false>;
+#define CS_PICK_S(E, RR, DD)                                                                       \
+  switch (sl) {                                                                                    \
+  case 1: CS_PICK_F(E, RR, DD, 1)                                                                  \
+  case 3: CS_PICK_F(E, RR, DD, 3)                                                                  \
+  default: CS_PICK_F(E, RR, DD, 0)                                                                 \
+  }
+#define CS_PICK(E)                                                                                 \
+  switch (r) {                                                                                     \
+  case 1: CS_PICK_S(E, 1, 2)                                                                       \
+  case 2: CS_PICK_S(E, 2, 2)                                                                       \
+  default: CS_PICK_S(E, 4, 2)                                                                      \
+  }
+  if (width == 1) { CS_PICK(unsigned char) }
+  CS_PICK(unsigned short)
+#undef CS_PICK
+#undef CS_PICK_S
+#undef CS_PICK_F
+}
+
 /* kernel 5: kernel 4 for small models, 64 / n_vars (2 or 4) nodes per wave; needs the 8-bit dense table (its
  * 16-bit LDS copy is relative to the pushing variable, cs_kernels.hip.h) */
 static int packed_nodes_per_wave(int fw, int n_vars, int dense_width) {
@@ -633,6 +662,8 @@ extern "C" int csgpu_model_finalize(csgpu_model *m) {
           for (int variant = 0; variant < 4; variant++)
             if ((rc = lds_limit(bytes, ne_regs_kernel(m->img->dense_width, m->fb_words, h->n_vars, variant & 1, variant >> 1))))
               return rc;
+          for (int full = 0; full < 2; full++)
+            if ((rc = lds_limit(bytes, ne_shave_kernel(m->img->dense_width, h->n_vars, m->img->dense_slots, full)))) return rc;
           m->packed_nw = 1; /* one set word per variable when every root domain has at most 32 values */
           for (int32_t v = 0; v < h->n_vars; v++)
             if ((int64_t)h->dom[v].hi - (int64_t)h->dom[v].lo + 1 > 32) m->packed_nw = 2;
@@ -681,13 +712,15 @@ extern "C" int csgpu_model_finalize(csgpu_model *m) {
 }
 
 extern "C" int csgpu_model_set_kernel(csgpu_model *m, int which) {
-  if (m == NULL || which < 0 || which > 6) return set_err(CSGPU_E_ARG, "bad argument");
+  if (m == NULL || which < 0 || which > 7) return set_err(CSGPU_E_ARG, "bad argument");
   if (which >= 2) {
     if (!m->finalized) return set_err(CSGPU_E_STATE, "model is not finalized");
     if (which == 2 && !m->lds_waves) return set_err(CSGPU_E_LIMIT, "model does not qualify for the LDS-resident kernel");
     if (which == 3 && !m->fb_words) return set_err(CSGPU_E_LIMIT, "model does not qualify for the forbidden-set kernel");
     if (which == 4 && !m->dense_waves)
       return set_err(CSGPU_E_LIMIT, "model does not qualify for the register-resident forbidden-set kernel");
+    if (which == 7 && !m->dense_waves)
+      return set_err(CSGPU_E_LIMIT, "model does not qualify for the interval-only shaving kernel (dense pair table in LDS)");
     if (which == 6 && !clause_rounds_cpl(m))
       return set_err(CSGPU_E_LIMIT, "model does not qualify for the clause-resident kernel (at most 512 clauses)");
     if (which == 5 && !(m->dense_waves && packed_nodes_per_wave(m->fb_words, m->host->n_vars, m->img->dense_width)))
@@ -704,6 +737,7 @@ extern "C" int csgpu_model_qualifies(const csgpu_model *m, int which) {
   case 2: return m->lds_waves != 0;
   case 3: return m->fb_words != 0;
   case 4: return m->dense_waves != 0;
+  case 7: return m->dense_waves != 0;
   case 6: return clause_rounds_cpl(m) != 0;
   case 5: return m->dense_waves != 0 && packed_nodes_per_wave(m->fb_words, m->host->n_vars, m->img->dense_width) != 0;
   default: return 0;
@@ -755,6 +789,34 @@ static int launch_regs(const csgpu_model *m, const csgpu_val *d_states_in, const
   const int fast = n == lanes && d_forb_in != NULL && d_forb_out != NULL && flags == 0;
   HIP_TRY(hipLaunchKernel(ne_regs_kernel(m->img->dense_width, m->fb_words, n, fast, sets_only), dim3((unsigned)g),
                           dim3((unsigned)(m->dense_waves * CS_WAVE)), args_d, m->dense_bytes, (hipStream_t)stream));
+  return CSGPU_OK;
+}
+
+/* kernel 7: intervals in, intervals out */
+static int launch_shave(const csgpu_model *m, const csgpu_val *d_states_in, const csgpu_node *d_nodes,
+                        csgpu_val *d_states_out, csgpu_result *d_results, int64_t batch, const uint64_t *d_batch,
+                        void *stream) {
+  int csz = CS_CHUNK;
+  {
+    const int64_t machine_waves = (int64_t)m->n_cus * 32;
+    while (csz > 1 && (batch + csz - 1) / csz < machine_waves) csz >>= 1;
+  }
+  const int64_t chunks = (batch + csz - 1) / csz;
+  size_t wgs = (160u * 1024u) / m->dense_bytes;
+  if (wgs > (size_t)(32 / m->dense_waves)) wgs = (size_t)(32 / m->dense_waves);
+  int64_t g = (int64_t)m->n_cus * (int64_t)wgs * 2; /* twice the resident grid, as kernel 4 */
+  const int64_t need_wg = (chunks + m->dense_waves - 1) / m->dense_waves;
+  if (g > need_wg) g = need_wg;
+  int n = m->host->n_vars, slots = m->img->dense_slots, dmin_d = m->img->dense_dmin;
+  const void *tab_d = m->d_dense_tab;
+  const int *root_lo_d = m->d_root_lo, *sym_off = m->d_sym_off;
+  long long nb_d = (long long)batch;
+  void *args[] = { &n, &tab_d, &slots, &dmin_d, &root_lo_d, &sym_off, &d_states_in, &d_nodes, &d_states_out, &d_results,
+                   &nb_d, &d_batch, &csz };
+  const int chunks_v = (n + CS_WAVE - 1) / CS_WAVE;
+  const int lanes = (chunks_v <= 1 ? 1 : (chunks_v <= 2 ? 2 : 4)) * CS_WAVE;
+  HIP_TRY(hipLaunchKernel(ne_shave_kernel(m->img->dense_width, n, slots, n == lanes), dim3((unsigned)g),
+                          dim3((unsigned)(m->dense_waves * CS_WAVE)), args, m->dense_bytes, (hipStream_t)stream));
   return CSGPU_OK;
 }
 
@@ -886,7 +948,9 @@ extern "C" int csgpu_model_get_kernel(const csgpu_model *m) {
   /* pure != networks: the forbidden-set kernels, the sets rebuilt from the incoming state when the caller
    * carries none (queens-64, 2^18 nodes: 0.14 ms against 0.51 ms of kernel 2; queens-16: 0.06 against 0.51) */
   if (m->fb_words) {
-    if (m->dense_waves) return packed_nodes_per_wave(m->fb_words, m->host->n_vars, m->img->dense_width) ? 5 : 4;
+    /* no sets passed: small models several nodes per wave with the sets rebuilt (5), otherwise the
+     * interval-only shaving kernel (7), which needs no sets at all */
+    if (m->dense_waves) return packed_nodes_per_wave(m->fb_words, m->host->n_vars, m->img->dense_width) ? 5 : 7;
     return 3;
   }
   if (m->lds_waves) return 2;
@@ -951,6 +1015,8 @@ extern "C" int csgpu_internal_propagate_objdev(const csgpu_model *m, const csgpu
     }
   }
   const int auto_kernel = csgpu_model_get_kernel(m);
+  if (auto_kernel == 7 && tab.obj_var < 0)
+    return launch_shave(m, d_states_in, d_nodes, d_states_out, d_results, batch, d_batch, stream);
   if (auto_kernel >= 3 && auto_kernel <= 5 && tab.obj_var < 0)
     return csgpu_internal_propagate_fb(m, d_states_in, NULL, d_nodes, d_states_out, NULL, d_results, batch, d_batch, stream);
   const unsigned long long *bdev = (const unsigned long long *)d_batch;

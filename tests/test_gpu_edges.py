@@ -16,14 +16,14 @@ def _oracle_for(text, model):
     return Oracle(om)
 
 
-def _check(text, nodes_fn, kernels=(1, 2, 3, 4, 5, 6), batch_sizes=(1, 3, 16, 17, 100)):
+def _check(text, nodes_fn, kernels=(1, 2, 3, 4, 5, 6, 7), batch_sizes=(1, 3, 16, 17, 100)):
     from csolve_amd.solver import solve_root
     model = solve_root(text)
     orc = _oracle_for(text, model)
     n = model.n_vars
     root = model.domains()
     rng = np.random.default_rng(5)
-    eligible = [k for k in (1, 2, 3, 4, 5, 6) if model.qualifies(k)]
+    eligible = [k for k in (1, 2, 3, 4, 5, 6, 7) if model.qualifies(k)]
     ran = []
     for k in kernels:
         if k not in eligible:

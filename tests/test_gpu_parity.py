@@ -42,6 +42,8 @@ def _kernels(model):
         ks.append(5)  # several nodes per wave (at most 32 variables)
     if model.qualifies(6):
         ks.append(6)  # small models: clauses resident in registers, all revised per round
+    if model.qualifies(7):
+        ks.append(7)  # interval states only: bounds shaved and verified on demand, no forbidden sets
     return ks
 
 
@@ -63,7 +65,7 @@ def test_reference_walks_on_reference_model(name):
     walk = read_walk(golden("walks", name + ".walk.gz"))
     model = Model.from_dump(golden("models", name + ".model")).finalize()
     if name in NE_ONLY:
-        assert model.kernel() in (3, 4, 5), "pure != networks of this size must take a forbidden-set kernel"
+        assert model.kernel() in (3, 4, 5, 7), "pure != networks of this size must take a forbidden-set or the shaving kernel"
     for k in _kernels(model):
         model.set_kernel(k)
         out, res = _gpu_walk(model, walk)
@@ -479,7 +481,7 @@ def test_all_kernels_agree_on_irregular_networks():
         o1, r1 = model.propagate(states_in, nodes)
         torch.cuda.synchronize()
         ok = r1[:, 0] >= 0
-        for k in (2, 3, 4, 5, 6):
+        for k in (2, 3, 4, 5, 6, 7):
             if not model.qualifies(k):
                 continue
             model.set_kernel(k)
@@ -492,7 +494,7 @@ def test_all_kernels_agree_on_irregular_networks():
             assert torch.equal(o[ok], o1[ok]), (seed, n, values, k)
             assert torch.equal(r[ok][:, :2], r1[ok][:, :2]), (seed, n, values, k)
             seen.add(k)
-    assert seen == {2, 3, 4, 5, 6}
+    assert seen == {2, 3, 4, 5, 6, 7}
 
 
 def test_linear_mixtures_through_both_general_kernels_and_the_oracle():

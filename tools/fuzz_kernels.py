@@ -29,7 +29,7 @@ for seed in range(models):
     torch.cuda.synchronize()
     ok = r1[:, 0] >= 0
     ran = [1]
-    for k in (2, 3, 4, 5, 6):
+    for k in (2, 3, 4, 5, 6, 7):
         if not model.qualifies(k):
             continue
         model.set_kernel(k)

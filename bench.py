@@ -292,7 +292,7 @@ def search_workload(args, rank, world, local, dist):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 200; 3 for --workload search, where a "
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 100; 3 for --workload search, where a "
                     "step is one complete search)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed steps before (default 10; 1 for --workload search)")
     ap.add_argument("--queens", type=int, default=64)
@@ -305,11 +305,13 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch the timed steps one by one instead of as one hipGraph")
     ap.add_argument("--kernel", type=int, default=0, help="0 best, 1 general, 2 LDS-resident, 3 forbidden sets in LDS, 4 forbidden sets in registers, "
-                         "5 = 4 with several nodes per wave (at most 32 variables), 6 clause-resident (small models)")
+                         "5 = 4 with several nodes per wave (at most 32 variables), 6 clause-resident (small models), 7 interval-only shaving")
     ap.add_argument("--rebuild-sets", action="store_true", help="forbidden-set kernel without resident sets")
-    ap.add_argument("--layout", choices=["intervals", "sets"], default="intervals",
-                    help="intervals: {lo,hi} states with the forbidden sets next to them (default); sets: the states are "
-                         "the forbidden sets alone (csgpu_propagate_batch_sets, kernel 4 models), half the bytes per node")
+    ap.add_argument("--layout", choices=["intervals", "intervals+sets", "sets"], default="intervals",
+                    help="which leg is the headline: intervals = the state-only entry csgpu_propagate_batch (default: "
+                         "interval states in and out, nothing precomputed); intervals+sets = csgpu_propagate_batch_fb "
+                         "with resident forbidden sets; sets = csgpu_propagate_batch_sets (bit-vector states)")
+    ap.add_argument("--no-queens128", action="store_true", help="skip the queens-128 sub-record of the default run")
     ap.add_argument("--workload", choices=["propagate", "search"], default="propagate")
     ap.add_argument("--search-queens", type=int, default=17, help="queens-N tree of the search workload (ALL: 17 is "
                     "95,815,104 solutions, 6.2e9 nodes, about a second on one GPU)")
@@ -327,15 +329,18 @@ def main():
     ap.add_argument("--same-device", action="store_true", help="all ranks on cuda:0 (rehearsal on a 1-GPU box, use --comm gloo)")
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = 3 if args.workload == "search" else 200
+        args.steps = 3 if args.workload == "search" else 100
     if args.warmup is None:
         args.warmup = 1 if args.workload == "search" else 10
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        # one process per GPU, started by the launcher: measuring one GPU under the label of N would be wrong,
+        # and starting the ranks from here would mean replacing a process that has already touched the GPU
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start the ranks with "
+                         f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...`")
     if args.same_device:
         local = 0
     torch.cuda.set_device(local)
@@ -355,64 +360,83 @@ def main():
     n_q = args.queens
     text = problems.queens(n_q)
     problem_name = f"queens-{n_q} "
+    workload_key = f"queens-{n_q}"
     if args.sudoku:
         text = problems.sudoku(args.sudoku, 0.3, 1)
         problem_name = f"sudoku-{args.sudoku ** 2}x{args.sudoku ** 2} (30 % givens) "
+        workload_key = f"sudoku-{args.sudoku ** 2}x{args.sudoku ** 2}"
     if args.schedule:
         text = problems.schedule(args.schedule, 1)
         problem_name = f"schedule-{args.schedule} (examples/schedule.txt style, MIN) "
-    model = solve_root(text)
-    # kernel: 0 = best available (forbidden-set kernel with the sets resident next to the states, in
-    # registers when the model qualifies), 1 general, 2 LDS-resident unit shaving, 3 / 4 forbidden sets
-    # in LDS / in registers
-    fw = model.forbidden_words()
-    use_sets = fw > 0 and args.kernel in (0, 3, 4, 5) and not args.rebuild_sets
-    forced = args.kernel
-    model.set_kernel(forced)
-    if use_sets or args.kernel in (3, 4, 5):
-        kernel_name = "cs_propagate_ne_regs" if (forced in (0, 4) and model.qualifies(4)) else "cs_propagate_ne_bitset"
-        if forced in (0, 5) and model.qualifies(5) and args.layout == "intervals":
-            kernel_name = "cs_propagate_ne_packed"
-    else:
-        kernel_name = {1: "cs_propagate_events", 2: "cs_propagate_ne_lds", 3: "cs_propagate_ne_bitset", 4: "cs_propagate_ne_regs",
-                       5: "cs_propagate_ne_packed", 6: "cs_propagate_clause_rounds", 7: "cs_propagate_ne_shave"}[model.kernel()]
-    n = model.n_vars
+        workload_key = f"schedule-{args.schedule}"
+    legs = run_propagation_legs(args, text, args.instances, seed=12345 + rank, dist=dist, headline_only=(world > 1))
+    head = legs["legs"][legs["headline"]]
+    model, n, B = legs["model"], legs["n"], legs["B"]
+    res_h = head["results"]
+    elapsed = torch.tensor([head["wall_s"]], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+    ok = res_h[:, 0] >= 0
+    # value: narrowing events of the consistent nodes only -- there the device count IS the reference's PROPS
+    # (every instance is re-checked against the compiled reference below); an inconsistent node's count depends on
+    # the revision order and is left out
+    totals = torch.tensor([res_h[ok, 1].sum(), res_h[:, 2].sum(), B, int((~ok).sum())], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(totals, op=dist.ReduceOp.SUM)
+    props_all, revs_all, nodes_all, fails_all = [float(x) for x in totals.tolist()]
     info = model.device_info()
+    steps = head["steps"]
+    out = {
+        "metric": "constraint propagations/sec + nodes/sec, queens-N, 1/2/4/8 MI355X",
+        "value": props_all * steps / elapsed,
+        "unit": "propagations/s",
+        "nodes_per_s": nodes_all * steps / elapsed,
+        "revisions_per_s": revs_all * steps / elapsed,
+        "n_gpus": world,
+        "steps": steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "int32",
+        "data": "synthetic",
+        "config": {"workload": f"{problem_name}propagation-only fixpoint (BASELINE configs[{4 if args.schedule else (2 if args.sudoku else 1)}]), seeded random-walk "
+                               f"node instances resident in HBM",
+                   "instances_per_gpu": B, "variables": n, "clauses": info["ne_clauses"] + info["tree_clauses"],
+                   "entry": head["entry"], "forbidden_sets_precomputed": head["sets_precomputed"],
+                   "value_counts": "PROPS of consistent nodes (equal to the reference's, re-checked per instance)",
+                   "inconsistent_fraction": fails_all / nodes_all,
+                   "props_per_consistent_node": props_all / max(1.0, nodes_all - fails_all),
+                   "revisions_per_node": revs_all / nodes_all},
+        "roofline": roofline_record(head, workload_key, B),
+    }
+    if not legs["headline_only"]:
+        out["legs"] = {k: leg_summary(v) for k, v in legs["legs"].items()}
+    if rank == 0 and world == 1 and not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(args, text, model, legs["states_in"], legs["nodes"], head["states_out"], res_h)
+        if not (args.sudoku or args.schedule) and n_q == 64 and not args.no_queens128:
+            out["queens128"] = queens128_record(args)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
 
-    states_in, nodes, forb_in = make_instances(model, args.instances, seed=12345 + rank, with_sets=use_sets,
-                                               restore_kernel=forced)
-    B = nodes.shape[0]
-    states_out = torch.empty((B, n, 2), dtype=torch.int32, device="cuda")
-    results = torch.empty((B, 4), dtype=torch.int32, device="cuda")
-    forb_out = torch.empty((B, n, fw), dtype=torch.int64, device="cuda") if use_sets else None
-    sets_only = args.layout == "sets"
-    if sets_only:
-        if not (use_sets and model.qualifies(4) and forced in (0, 4)):
-            raise SystemExit("--layout sets needs a model that qualifies for kernel 4 (and --kernel 0 or 4)")
-        sets_in = model.pack_sets(states_in)
-        torch.cuda.synchronize()
 
-    def step():
-        if sets_only:
-            model.propagate_sets(sets_in, nodes, sets_out=forb_out, results=results)
-        elif use_sets:
-            model.propagate_fb(states_in, nodes, forb_in=forb_in, states_out=states_out, forb_out=forb_out,
-                               results=results)
-        else:
-            model.propagate(states_in, nodes, states_out, results)
-
+def time_steps(step, steps, warmup, use_graph, dist=None):
+    """warmup launches, then `steps` launches captured into one hipGraph (or launched one by one) between HIP
+    events on the launching stream and between two barriers.  -> (kernel_ms per launch, wall seconds, launch kind)"""
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     barrier()
-    # The K timed launches are captured into one hipGraph (the loop is launch-bound on the host side: ~5 % of a
-    # 0.1 ms kernel per launch otherwise) and replayed once inside the timed region; HIP events bracket the replay.
     graph = None
-    if not args.no_graph:
+    if use_graph:
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -422,7 +446,7 @@ def main():
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=side):
-                for k in range(args.steps):
+                for _ in range(steps):
                     step()
             graph.replay()  # one untimed replay: instantiation and upload of the graph
             barrier()
@@ -431,89 +455,147 @@ def main():
             graph = None
             torch.cuda.synchronize()
     if graph is not None:
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
-        ev[0][0].record()
+        e0.record()
         graph.replay()
-        ev[0][1].record()
+        e1.record()
         barrier()
         t1 = time.perf_counter()
-    else:
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-        t0 = time.perf_counter()
-        for k in range(args.steps):
-            ev[k][0].record()
-            step()
-            ev[k][1].record()
-        barrier()
-        t1 = time.perf_counter()
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device="cuda")
-    if dist is not None:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    elapsed = float(elapsed.item())
+        return e0.elapsed_time(e1) / steps, t1 - t0, "one hipGraph of the timed launches"
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for k in range(steps):
+        ev[k][0].record()
+        step()
+        ev[k][1].record()
+    barrier()
+    t1 = time.perf_counter()
+    return float(np.sum([a.elapsed_time(b) for a, b in ev])) / steps, t1 - t0, "launch loop"
 
-    if sets_only:
-        states_out = model.unpack_sets(forb_out)  # for the check against the CPU reference below
-    res_h = results.cpu().numpy().astype(np.int64)
-    totals = torch.tensor([res_h[:, 1].sum(), res_h[:, 2].sum(), B, int((res_h[:, 0] < 0).sum())],
-                          dtype=torch.float64, device="cuda")
-    if dist is not None:
-        dist.all_reduce(totals, op=dist.ReduceOp.SUM)
-    props_all, revs_all, nodes_all, fails_all = [float(x) for x in totals.tolist()]
 
-    kernel_ms = float(np.sum([a.elapsed_time(b) for a, b in ev])) / args.steps  # average launch duration
-    props_r, revs_r = int(res_h[:, 1].sum()), int(res_h[:, 2].sum())
-    # Algorithmic bytes of one launch = what the kernel's data layout obliges it to move over HBM
-    # (DESIGN.md 2/4): per node instance the state in and out (16 B x n), the forbidden sets in and
-    # out when they are resident (16 B x n x FW), the 16-B node record and the 16-B result.
-    # The clause tables are read once per workgroup from L2 and are not counted.
-    # An inconsistent node has no output row: only the register-resident kernel on models that fill its
-    # lanes (n = 64, 128, 256: straight-line stores) writes a (meaningless) row for it
-    # anyway, every other kernel stores the rows of consistent nodes only -- and only those are counted.
-    row_in = (0 if sets_only else 8 * n) + (8 * n * fw if use_sets else 0)
-    stores_all = (kernel_name == "cs_propagate_ne_regs" and n in (64, 128, 256) and use_sets) or \
-                 (kernel_name == "cs_propagate_ne_shave" and n in (64, 128, 256))
-    stored = B if stores_all else int((res_h[:, 0] >= 0).sum())
-    alg_bytes = (row_in + 16 + 16) * B + row_in * stored
-    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-    # SURVEY 8(d) also prices every clause revision as 32 B of memory traffic (+ 8 B per narrowing);
-    # in this design those bytes are LDS traffic, so that figure is reported separately
-    survey_bytes = 32 * revs_r + 8 * props_r + 16 * n * B
-    out = {
-        "metric": "constraint propagations/sec + nodes/sec, queens-N, 1/2/4/8 MI355X",
-        "value": props_all * args.steps / elapsed,
-        "unit": "propagations/s",
-        "nodes_per_s": nodes_all * args.steps / elapsed,
-        "revisions_per_s": revs_all * args.steps / elapsed,
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "int32",
-        "data": "synthetic",
-        "config": {"workload": f"{problem_name}propagation-only fixpoint (BASELINE configs[{4 if args.schedule else (2 if args.sudoku else 1)}]), seeded random-walk "
-                               f"node instances resident in HBM",
-                   "instances_per_gpu": B, "variables": n, "forbidden_sets_resident": bool(use_sets), "layout": args.layout, "clauses": info["ne_clauses"] + info["tree_clauses"],
-                   "inconsistent_fraction": fails_all / nodes_all,
-                   "props_per_node": props_all / nodes_all, "revisions_per_node": revs_all / nodes_all},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None if (args.schedule or sets_only) else measured_traffic(
-                         kernel_name, f"sudoku-{args.sudoku ** 2}x{args.sudoku ** 2}" if args.sudoku else f"queens-{n_q}", B),
-                     "kernel": kernel_name, "kernel_ms": kernel_ms, "launch": "one hipGraph of the timed launches" if graph is not None else "launch loop",
-                     "algorithmic_bytes_per_launch": alg_bytes,
-                     "bytes_per_node_instance": alg_bytes // B, "output_rows_stored": stored,
-                     "survey_8d_formula_gbps": survey_bytes / (kernel_ms * 1e-3) / 1e9},
-    }
+def run_propagation_legs(args, text, instances, seed, dist=None, headline_only=False, steps=None):
+    """The batched fixpoint over one resident instance set, through the entries of the C ABI:
+      state_only     csgpu_propagate_batch: interval states in, interval states out, nothing precomputed -- what
+                     propagate_clauses is defined on and what the CPU baseline gets (the headline where it exists)
+      resident_sets  csgpu_propagate_batch_fb: intervals + forbidden sets carried with every state (the search
+                     engine's layout); the sets of the inputs are built by an untimed launch
+      sets_only      csgpu_propagate_batch_sets: the states carried as bit vectors alone
+    Each leg is timed on its own with the same number of steps."""
+    model = solve_root(text)
+    forced = args.kernel
+    model.set_kernel(forced)
+    fw = model.forbidden_words()
+    n = model.n_vars
+    steps = steps or args.steps
+    want_sets = fw > 0 and forced in (0, 3, 4, 5) and not args.rebuild_sets
+    states_in, nodes, forb_in = make_instances(model, instances, seed=seed, with_sets=want_sets, restore_kernel=forced)
+    B = nodes.shape[0]
+    legs = {}
 
-    if rank == 0 and world == 1 and not args.no_cpu:
-        out["cpu_baseline"] = cpu_baseline(args, text, model, states_in, nodes, states_out, res_h)
-    if rank == 0:
-        print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+    def leg(name, entry, kernel_name, step, states_out, results, layout_bytes_per_node, stores_all, sets_precomputed,
+            finish=None):
+        kernel_ms, wall, launch = time_steps(step, steps, args.warmup, not args.no_graph, dist)
+        res_h = results.cpu().numpy().astype(np.int64)
+        so = finish() if finish is not None else states_out
+        stored = B if stores_all else int((res_h[:, 0] >= 0).sum())
+        legs[name] = {"entry": entry, "kernel": kernel_name, "kernel_ms": kernel_ms, "wall_s": wall, "launch": launch,
+                      "steps": steps, "results": res_h, "states_out": so, "n": n, "B": B,
+                      "sets_precomputed": sets_precomputed,
+                      # what this layout moves: rows in for every node, rows out for the stored ones, record + result
+                      "layout_bytes": (layout_bytes_per_node + 32) * B + layout_bytes_per_node * stored,
+                      "stored_rows": stored}
+
+    auto = model.kernel()
+    names = {1: "cs_propagate_events", 2: "cs_propagate_ne_lds", 3: "cs_propagate_ne_bitset", 4: "cs_propagate_ne_regs",
+             5: "cs_propagate_ne_packed", 6: "cs_propagate_clause_rounds", 7: "cs_propagate_ne_shave"}
+    # --- state only (every model) ---
+    so1 = torch.empty((B, n, 2), dtype=torch.int32, device="cuda")
+    r1 = torch.empty((B, 4), dtype=torch.int32, device="cuda")
+    k1 = names[auto]
+    full_lanes = n in (64, 128, 256)
+    leg("state_only", "csgpu_propagate_batch (interval states in, interval states out)", k1,
+        lambda: model.propagate(states_in, nodes, so1, r1), so1, r1, 8 * n,
+        stores_all=(k1 == "cs_propagate_ne_shave" and full_lanes), sets_precomputed=False)
+    headline = "state_only"
+    if want_sets and not headline_only:
+        so2 = torch.empty((B, n, 2), dtype=torch.int32, device="cuda")
+        r2 = torch.empty((B, 4), dtype=torch.int32, device="cuda")
+        fo2 = torch.empty((B, n, fw), dtype=torch.int64, device="cuda")
+        k2 = "cs_propagate_ne_packed" if (forced in (0, 5) and model.qualifies(5)) else \
+            ("cs_propagate_ne_regs" if (forced in (0, 4, 5) and model.qualifies(4)) else "cs_propagate_ne_bitset")
+        leg("resident_sets", "csgpu_propagate_batch_fb (intervals + forbidden sets in, the same out)", k2,
+            lambda: model.propagate_fb(states_in, nodes, forb_in=forb_in, states_out=so2, forb_out=fo2, results=r2),
+            so2, r2, 8 * n + 8 * n * fw, stores_all=(k2 == "cs_propagate_ne_regs" and full_lanes), sets_precomputed=True)
+        if model.qualifies(4) and forced in (0, 4):
+            sets_in = model.pack_sets(states_in)
+            torch.cuda.synchronize()
+            fo3 = torch.empty((B, n, fw), dtype=torch.int64, device="cuda")
+            r3 = torch.empty((B, 4), dtype=torch.int32, device="cuda")
+            leg("sets_only", "csgpu_propagate_batch_sets (bit-vector states in, bit-vector states out)",
+                "cs_propagate_ne_regs",
+                lambda: model.propagate_sets(sets_in, nodes, sets_out=fo3, results=r3), None, r3, 8 * n * fw,
+                stores_all=full_lanes, sets_precomputed=True, finish=lambda: model.unpack_sets(fo3))
+    if args.layout == "sets" and "sets_only" in legs:
+        headline = "sets_only"
+    elif args.layout == "intervals+sets" and "resident_sets" in legs:
+        headline = "resident_sets"
+    return {"legs": legs, "headline": headline, "model": model, "n": n, "B": B, "states_in": states_in, "nodes": nodes,
+            "headline_only": headline_only}
+
+
+def roofline_record(leg, workload_key, B):
+    """HBM roofline of one leg.  `achieved` / `frac` are on the NECESSARY bytes of a node instance -- the state in
+    and out (`struct val_t` per variable: 16 n) plus the 16-byte node record and the 16-byte result --
+    whatever the layout of the leg moves on top of that is reported as layout_*."""
+    n = leg["n"]
+    necessary = (16 * n + 32) * B
+    t = leg["kernel_ms"] * 1e-3
+    res_h = leg["results"]
+    survey_bytes = 32 * int(res_h[:, 2].sum()) + 8 * int(res_h[:, 1].sum()) + 16 * n * B
+    traffic = measured_traffic(leg["kernel"], workload_key, B)
+    return {"bound": "hbm", "achieved": necessary / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": necessary / t / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+            "kernel": leg["kernel"], "kernel_ms": leg["kernel_ms"], "launch": leg["launch"],
+            "algorithmic_bytes_per_launch": necessary, "bytes_per_node_instance": 16 * n + 32,
+            "layout_bytes_per_launch": leg["layout_bytes"], "layout_gbps": leg["layout_bytes"] / t / 1e9,
+            "layout_frac": leg["layout_bytes"] / t / 1e9 / HBM_PEAK_GBS,
+            "traffic_over_necessary": None if traffic is None else traffic / necessary,
+            "output_rows_stored": leg["stored_rows"],
+            "survey_8d_formula_gbps": survey_bytes / t / 1e9}
+
+
+def leg_summary(leg):
+    B, n, t = leg["B"], leg["n"], leg["kernel_ms"] * 1e-3
+    ok = leg["results"][:, 0] >= 0
+    return {"entry": leg["entry"], "kernel": leg["kernel"], "kernel_ms": leg["kernel_ms"], "nodes_per_s": B / t,
+            "propagations_per_s": int(leg["results"][ok, 1].sum()) / t,
+            "forbidden_sets_precomputed": leg["sets_precomputed"],
+            "frac_of_hbm_peak_on_necessary_bytes": (16 * n + 32) * B / t / 1e9 / HBM_PEAK_GBS,
+            "frac_of_hbm_peak_on_layout_bytes": leg["layout_bytes"] / t / 1e9 / HBM_PEAK_GBS,
+            "layout_bytes_per_node": leg["layout_bytes"] / B}
+
+
+def queens128_record(args):
+    """The north-star instance next to the headline: queens-128, 2^17 seeded node instances, state-only entry,
+    every instance re-checked against the compiled reference (one pass, about 3 s of one host core)."""
+    import copy
+    a = copy.copy(args)
+    a.queens, a.sudoku, a.schedule, a.layout = 128, 0, 0, "intervals"
+    a.cpu_seconds = min(args.cpu_seconds, 6.0)
+    text = problems.queens(128)
+    legs = run_propagation_legs(a, text, 1 << 17, seed=777, headline_only=True, steps=min(args.steps, 50))
+    leg = legs["legs"]["state_only"]
+    rec = roofline_record(leg, "queens-128", legs["B"])
+    ok = leg["results"][:, 0] >= 0
+    t = leg["kernel_ms"] * 1e-3
+    out = {"workload": "queens-128 propagation-only fixpoint, 131072 seeded random-walk node instances resident in HBM",
+           "entry": leg["entry"], "forbidden_sets_precomputed": False, "steps": leg["steps"],
+           "nodes_per_s": legs["B"] / t, "value": int(leg["results"][ok, 1].sum()) / t, "unit": "propagations/s",
+           "roofline": rec}
+    out["cpu_baseline"] = cpu_baseline(a, text, legs["model"], legs["states_in"], legs["nodes"], leg["states_out"], leg["results"])
+    out["speedup_over_reference_core"] = out["value"] / out["cpu_baseline"]["value"]
+    return out
 
 
 if __name__ == "__main__":

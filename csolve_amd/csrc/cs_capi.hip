@@ -9,6 +9,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "../../include/csolve_gpu.h"
 #include "cs_kernels.hip.h"
 #include "cs_shave.hip.h"
@@ -33,6 +35,10 @@ extern "C" int csgpu_internal_set_error(int code, const char *msg) { return set_
     if (e_ != hipSuccess)                                                      \
       return set_err(CSGPU_E_HIP, "%s: %s", #expr, hipGetErrorString(e_));     \
   } while (0)
+
+#define CS_TICKET_SLOTS 1024
+#define CS_TICKET_STREAMS 64
+#define CS_TICKET_SLOT_WORDS (CS_SHAVE_SHARDS * CS_SHAVE_TICKET_STRIDE)
 
 struct csgpu_model {
   cs_model *host;
@@ -64,6 +70,13 @@ struct csgpu_model {
   int *d_sym_off;
   void *d_sym_packed;
   int n_cus;
+  /* kernel 7: ticket counters of its work distribution (cs_shave.hip.h).  One slot (CS_SHAVE_SHARDS counters on
+   * their own 64-byte lines) per stream that launches it -- launches of one stream are ordered, and the kernel
+   * leaves its counters at zero -- and one slot of its own for every launch that is being captured into a
+   * hipGraph (graphs captured on one stream may be replayed on different ones at the same time). */
+  unsigned *d_tickets;
+  int ticket_slots, ticket_streams, ticket_reserved;
+  void *ticket_stream[CS_TICKET_STREAMS];
   /* staging of csgpu_propagate_one */
   /* pinned host memory mapped into the device's address space: the kernel reads the state and the node record
    * from it and writes the result and the new state back, no staging copies */
@@ -158,6 +171,9 @@ static void free_device(csgpu_model *m) {
   (void)hipFree(m->d_dense_tab);
   (void)hipFree(m->d_packed_tab);
   m->d_packed_tab = NULL;
+  (void)hipFree(m->d_tickets);
+  m->d_tickets = NULL;
+  m->ticket_slots = m->ticket_streams = m->ticket_reserved = 0;
   m->d_sym_off = NULL;
   m->d_sym_packed = NULL;
   m->d_dense_tab = NULL;
@@ -448,20 +464,20 @@ static const void *ne_shave_kernel(int width, int n_vars, int slots, int full) {
   const int chunks = (n_vars + CS_WAVE - 1) / CS_WAVE;
   const int r = chunks <= 1 ? 1 : (chunks <= 2 ? 2 : 4);
   const int sl = slots == 1 ? 1 : (slots == 3 ? 3 : 0);
-#define CS_PICK_F(E, RR, DD, SS)                                                                   \
-  return full ? (const void *)cs_propagate_ne_shave<E, RR, DD, SS, true>                            \
-              : (const void *)cs_propagate_ne_shave<E, RR, DD, SS, false>;
-#define CS_PICK_S(E, RR, DD)                                                                       \
+#define CS_PICK_F(E, RR, SS)                                                                       \
+  return full ? (const void *)cs_propagate_ne_shave<E, RR, SS, true>                                \
+              : (const void *)cs_propagate_ne_shave<E, RR, SS, false>;
+#define CS_PICK_S(E, RR)                                                                           \
   switch (sl) {                                                                                    \
-  case 1: CS_PICK_F(E, RR, DD, 1)                                                                  \
-  case 3: CS_PICK_F(E, RR, DD, 3)                                                                  \
-  default: CS_PICK_F(E, RR, DD, 0)                                                                 \
+  case 1: CS_PICK_F(E, RR, 1)                                                                      \
+  case 3: CS_PICK_F(E, RR, 3)                                                                      \
+  default: CS_PICK_F(E, RR, 0)                                                                     \
   }
 #define CS_PICK(E)                                                                                 \
   switch (r) {                                                                                     \
-  case 1: CS_PICK_S(E, 1, 2)                                                                       \
-  case 2: CS_PICK_S(E, 2, 2)                                                                       \
-  default: CS_PICK_S(E, 4, 2)                                                                      \
+  case 1: CS_PICK_S(E, 1)                                                                          \
+  case 2: CS_PICK_S(E, 2)                                                                          \
+  default: CS_PICK_S(E, 4)                                                                         \
   }
   if (width == 1) { CS_PICK(unsigned char) }
   CS_PICK(unsigned short)
@@ -664,6 +680,9 @@ extern "C" int csgpu_model_finalize(csgpu_model *m) {
               return rc;
           for (int full = 0; full < 2; full++)
             if ((rc = lds_limit(bytes, ne_shave_kernel(m->img->dense_width, h->n_vars, m->img->dense_slots, full)))) return rc;
+          HIP_TRY(hipMalloc((void **)&m->d_tickets, (size_t)CS_TICKET_SLOTS * CS_TICKET_SLOT_WORDS * sizeof(unsigned)));
+          HIP_TRY(hipMemset(m->d_tickets, 0, (size_t)CS_TICKET_SLOTS * CS_TICKET_SLOT_WORDS * sizeof(unsigned)));
+          m->ticket_slots = CS_TICKET_SLOTS;
           m->packed_nw = 1; /* one set word per variable when every root domain has at most 32 values */
           for (int32_t v = 0; v < h->n_vars; v++)
             if ((int64_t)h->dom[v].hi - (int64_t)h->dom[v].lo + 1 > 32) m->packed_nw = 2;
@@ -793,32 +812,63 @@ static int launch_regs(const csgpu_model *m, const csgpu_val *d_states_in, const
 }
 
 /* kernel 7: intervals in, intervals out */
+static std::mutex g_ticket_mutex;
+
+/* the ticket slot of a launch on `stream` (NULL: none left, the kernel then uses static shares) */
+static unsigned *ticket_slot(csgpu_model *m, void *stream) {
+  if (m->d_tickets == NULL) return NULL;
+  std::lock_guard<std::mutex> lock(g_ticket_mutex);
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (stream != NULL && hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
+  int slot = -1;
+  if (cap == hipStreamCaptureStatusActive) {
+    /* a captured launch keeps a slot of its own for good (taken from the top) */
+    if (m->ticket_reserved < m->ticket_slots - CS_TICKET_STREAMS) slot = m->ticket_slots - 1 - m->ticket_reserved++;
+  } else {
+    for (int i = 0; i < m->ticket_streams; i++)
+      if (m->ticket_stream[i] == stream) slot = i;
+    if (slot < 0 && m->ticket_streams < CS_TICKET_STREAMS) {
+      slot = m->ticket_streams++;
+      m->ticket_stream[slot] = stream;
+    }
+  }
+  return slot < 0 ? NULL : m->d_tickets + (size_t)slot * CS_TICKET_SLOT_WORDS;
+}
+
 static int launch_shave(const csgpu_model *m, const csgpu_val *d_states_in, const csgpu_node *d_nodes,
                         csgpu_val *d_states_out, csgpu_result *d_results, int64_t batch, const uint64_t *d_batch,
                         void *stream) {
-  int csz = CS_CHUNK;
-  {
-    const int64_t machine_waves = (int64_t)m->n_cus * 32;
-    while (csz > 1 && (batch + csz - 1) / csz < machine_waves) csz >>= 1;
-  }
+  /* two nodes per chunk; a batch smaller than the machine is spread one node per wave */
+  int csz = CS_SHAVE_CHUNK;
+  const int64_t machine_waves = (int64_t)m->n_cus * 32;
+  if ((batch + csz - 1) / csz < machine_waves) csz = 1;
   const int64_t chunks = (batch + csz - 1) / csz;
   size_t wgs = (160u * 1024u) / m->dense_bytes;
   if (wgs > (size_t)(32 / m->dense_waves)) wgs = (size_t)(32 / m->dense_waves);
-  int64_t g = (int64_t)m->n_cus * (int64_t)wgs * 2; /* twice the resident grid, as kernel 4 */
+  int64_t g = (int64_t)m->n_cus * (int64_t)wgs; /* the resident grid: persistent waves, work drawn by ticket */
   const int64_t need_wg = (chunks + m->dense_waves - 1) / m->dense_waves;
   if (g > need_wg) g = need_wg;
   int n = m->host->n_vars, slots = m->img->dense_slots, dmin_d = m->img->dense_dmin;
   const void *tab_d = m->d_dense_tab;
   const int *root_lo_d = m->d_root_lo, *sym_off = m->d_sym_off;
   long long nb_d = (long long)batch;
+  unsigned *tickets = getenv("CSGPU_SHAVE_STATIC") != NULL ? NULL : ticket_slot((csgpu_model *)m, stream);
   void *args[] = { &n, &tab_d, &slots, &dmin_d, &root_lo_d, &sym_off, &d_states_in, &d_nodes, &d_states_out, &d_results,
-                   &nb_d, &d_batch, &csz };
+                   &nb_d, &d_batch, &csz, &tickets };
   const int chunks_v = (n + CS_WAVE - 1) / CS_WAVE;
   const int lanes = (chunks_v <= 1 ? 1 : (chunks_v <= 2 ? 2 : 4)) * CS_WAVE;
   HIP_TRY(hipLaunchKernel(ne_shave_kernel(m->img->dense_width, n, slots, n == lanes), dim3((unsigned)g),
                           dim3((unsigned)(m->dense_waves * CS_WAVE)), args, m->dense_bytes, (hipStream_t)stream));
   return CSGPU_OK;
 }
+
+#ifdef CS_SHAVE_TIMELINE
+extern "C" int csgpu_debug_shave_timeline(unsigned long long *out, int waves) {
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(cs_shave_tl), (size_t)waves * 3 * sizeof(unsigned long long)));
+  return CSGPU_OK;
+}
+#endif
 
 extern "C" int csgpu_propagate_batch_fb(const csgpu_model *m, const csgpu_val *d_states_in, const uint64_t *d_forb_in,
                                         const csgpu_node *d_nodes, csgpu_val *d_states_out, uint64_t *d_forb_out,

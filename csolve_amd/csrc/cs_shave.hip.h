@@ -28,30 +28,67 @@
  * var < 0 ("propagate everything") pushes every valued variable.
  *
  * One wavefront per node, lane l owns variables l, l + 64, ... (R of them); bounds live in VGPRs relative
- * to the variable's root lower bound; masks of valued / pushed / dirty variables are 64-bit scalars; D
- * parent rows are in flight per wave (register prefetch).  LDS holds the table only.
+ * to the variable's root lower bound; masks of valued / pushed / dirty variables are 64-bit scalars.  LDS holds
+ * the table only.
+ *
+ * Work distribution.  Nodes cost very different amounts (a node is 1 to 60 table-row operations), and with
+ * static shares the waves of a launch finished anywhere between 30 and 119 us of a 119 us launch (mean
+ * residency 0.5, tools/shave_timeline.py).  So the waves are persistent (one resident grid) and take their
+ * work in chunks of two nodes from ticket counters in device memory: chunk c belongs to shard c mod S
+ * (S <= 64 counters, each on its own 64-byte line, a workgroup uses shard blockIdx mod S; a single word
+ * sustains about 88 atomics per microsecond, MI355X_MICROARCH.md), a wave's first chunk is static, the next
+ * ones are ticket numbers.  Every wave stops at its first ticket past the end, so a launch draws exactly
+ * "chunks of the shard" tickets per counter, and the wave that draws the last one resets the counter: no
+ * host-side clearing, safe under hipGraph replay.  The pipeline of a wave, one chunk per step: ticket for
+ * chunk k + 2 (atomic in flight), node records of chunk k + 1 (load in flight), parent rows of chunk k + 1
+ * (loads in flight), fixpoints of chunk k.  Without a ticket buffer (tickets == NULL) or with fewer chunks
+ * than waves the shares are static (chunk index strides by the number of waves of the shard).
  */
 #ifndef CS_SHAVE_HIP_H
 #define CS_SHAVE_HIP_H
 
 #include "cs_kernels.hip.h"
 
+#ifdef CS_SHAVE_TIMELINE
+/* diagnostic build only (tools/shave_timeline.py): start, end (100 MHz real-time counter) and node count per wave */
+__device__ unsigned long long cs_shave_tl[3 * 65536];
+#endif
+
+/* clear bit `i` of a wave-uniform 64-bit mask: one scalar instruction (the compiler's `m &= m - 1` is three) */
+__device__ __forceinline__ unsigned long long cs_bitset0(unsigned long long m, int i) {
+  asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(i));
+  return m;
+}
+
+#define CS_SHAVE_CHUNK 2        /* nodes per chunk = parent rows in flight per wave */
+#define CS_SHAVE_SHARDS 64      /* ticket counters per launch at most */
+#define CS_SHAVE_TICKET_STRIDE 16 /* unsigned words between two counters: one 64-byte line each */
+
 /* SL: slots per pair known at compile time (1 = alldiff-style, 3 = queens), 0 = run-time loop.
  * FULL: n == 64 R, every lane register holds a variable: loads and stores are unconditional. */
-template <typename E, int R, int D, int SL, bool FULL>
+template <typename E, int R, int SL, bool FULL>
 __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_shave(
     int n, const E *__restrict__ tab_g, int slots, int dmin, const int *__restrict__ root_lo,
     const int *__restrict__ sym_off, const cs_val *__restrict__ states_in, const cs_node_in *__restrict__ nodes,
     cs_val *__restrict__ states_out, cs_node_out *__restrict__ results, long long batch,
-    const unsigned long long *__restrict__ batch_dev, int csz) {
+    const unsigned long long *__restrict__ batch_dev, int csz /* 1 or 2 nodes per chunk */, unsigned *tickets) {
   extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
   typedef unsigned long long u64;
   constexpr int W = CS_WAVE * R; /* columns of the table */
+  constexpr int D = CS_SHAVE_CHUNK;
   if (batch_dev != nullptr && (long long)*batch_dev < batch) batch = (long long)*batch_dev;
   const int lane = threadIdx.x & (CS_WAVE - 1);
   const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int waves_per_block = blockDim.x >> 6;
-  if ((long long)blockIdx.x * waves_per_block * csz >= batch) return; /* no node for this workgroup */
+  const int chunks = (int)((batch + csz - 1) / csz); /* the ABI's batches stay below 2^31 nodes */
+  /* shards: chunk c belongs to shard c mod nsh, local index c / nsh; workgroup b works on shard b mod nsh */
+  const int nsh = (int)gridDim.x < CS_SHAVE_SHARDS ? (int)gridDim.x : CS_SHAVE_SHARDS;
+  const int shard = (int)(blockIdx.x % nsh);
+  const int count_x = chunks > shard ? (chunks - 1 - shard) / nsh + 1 : 0; /* chunks of this shard */
+  const int waves_x = (((int)gridDim.x - 1 - shard) / nsh + 1) * waves_per_block;
+  const int wave_local = (int)(blockIdx.x / nsh) * waves_per_block + wave_in_block;
+  const bool dynamic = tickets != nullptr && count_x > waves_x;
+  if ((int)(blockIdx.x / nsh) * waves_per_block >= count_x) return; /* no chunk for any wave of this workgroup */
   if (SL != 0) slots = SL;
   const E *s_tab = (const E *)cs_lds;
   {
@@ -60,7 +97,12 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_shave(
     uint4 *dst = (uint4 *)cs_lds;
     for (int i = threadIdx.x; i < vecs; i += blockDim.x) dst[i] = src[i];
   }
+#ifdef CS_SHAVE_TIMELINE
+  const unsigned long long tl_start = __builtin_amdgcn_s_memrealtime();
+  unsigned long long tl_nodes = 0;
+#endif
   __syncthreads();
+  if (wave_local >= count_x) return;
 
   int b0[R], kb[R], deg[R], vcl[R];
   bool live[R];
@@ -76,240 +118,345 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_shave(
   u64 livemask[R]; /* lanes that hold a variable: the others look like values and must never push or forbid */
 #pragma unroll
   for (int r = 0; r < R; r++) livemask[r] = FULL ? ~0ull : __ballot(live[r]);
+  unsigned *my_ticket = tickets + (size_t)shard * CS_SHAVE_TICKET_STRIDE;
 
-  const long long chunks = (batch + csz - 1) / csz;
-  const long long waves_total = (long long)gridDim.x * waves_per_block;
-  for (long long chunk = (long long)blockIdx.x * waves_per_block + wave_in_block; chunk < chunks; chunk += waves_total) {
-    const long long base = chunk * csz;
-    const int cnt = (int)(batch - base < csz ? batch - base : csz);
+  /* the record of chunk i of this shard (lanes 0 .. csz-1); lanes past the end of the batch hold a no-op */
+  auto load_rec = [&](int i) {
     cs_node_in rec;
     rec.var = -1; rec.lo = 0; rec.hi = 0; rec.parent = 0;
-    if (lane < cnt) rec = nodes[base + lane];
+    const long long node = ((long long)i * nsh + shard) * csz + lane;
+    if (lane < csz && node < batch) rec = nodes[node];
+    return rec;
+  };
+  /* ticket -> local chunk index (a scalar); the wave that draws the shard's last ticket resets the counter */
+  auto next_index = [&](int i_prev, unsigned tk_v) -> int {
+    if (!dynamic) return i_prev + waves_x;
+    const int t = __builtin_amdgcn_readfirstlane((int)tk_v);
+    if (t == count_x - 1 && lane == 0) __hip_atomic_store(my_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return waves_x + t;
+  };
+  auto draw = [&]() -> unsigned { /* the ticket arrives in lane 0 */
+    unsigned tk_v = 0;
+    if (lane == 0) tk_v = __hip_atomic_fetch_add(my_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return tk_v;
+  };
+
+  /* prologue of the pipeline: chunk 0 is the wave's own, the ticket of chunk 1 is drawn at once */
+  int i_cur = wave_local;
+  cs_node_in rec_cur = load_rec(i_cur);
+  unsigned tk = dynamic ? draw() : 0u;
+  cs_val pd[D][R];
+#pragma unroll
+  for (int d = 0; d < D; d++) {
+    const size_t prow = (size_t)__builtin_amdgcn_readlane(rec_cur.parent, d) * n;
+#pragma unroll
+    for (int r = 0; r < R; r++) pd[d][r] = states_in[prow + vcl[r]];
+  }
+  int i_next = next_index(i_cur, tk);
+  int have_next = i_next < count_x;
+  cs_node_in rec_next = load_rec(have_next ? i_next : i_cur);
+
+  for (;;) {
+    /* the indices are wave-uniform by construction; say so (the compiler otherwise carries them in vector registers) */
+    i_cur = __builtin_amdgcn_readfirstlane(i_cur);
+    i_next = __builtin_amdgcn_readfirstlane(i_next);
+    have_next = __builtin_amdgcn_readfirstlane(have_next);
+    if (have_next && dynamic) tk = draw(); /* for the chunk after the next one */
+    cs_val pn[D][R]; /* parent rows of the next chunk (its records arrived during the previous step) */
+#pragma unroll
+    for (int d = 0; d < D; d++)
+#pragma unroll
+      for (int r = 0; r < R; r++) pn[d][r] = pd[d][r];
+    if (have_next) {
+#pragma unroll
+      for (int d = 0; d < D; d++) {
+        const size_t prow = (size_t)__builtin_amdgcn_readlane(rec_next.parent, d) * n;
+#pragma unroll
+        for (int r = 0; r < R; r++) pn[d][r] = states_in[prow + vcl[r]];
+      }
+    }
+    const long long base = ((long long)i_cur * nsh + shard) * csz;
+    const int cnt = (int)(batch - base < csz ? batch - base : csz);
+#ifdef CS_SHAVE_TIMELINE
+    tl_nodes += cnt;
+#endif
     cs_node_out my_result;
     my_result.status = 0; my_result.props = 0; my_result.revisions = 0; my_result.rounds = 0;
+#pragma unroll
+    for (int dd = 0; dd < D; dd++) {
+      const int j = dd;
+      if (j >= cnt) continue;
+      const int nvar = __builtin_amdgcn_readlane(rec_cur.var, j);
+      const int nlo = __builtin_amdgcn_readlane(rec_cur.lo, j), nhi = __builtin_amdgcn_readlane(rec_cur.hi, j);
+      int rlo[R], rhi[R]; /* bounds relative to the root lower bound; a lane without a variable is the value 0 */
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        rlo[r] = live[r] ? pd[dd][r].lo - b0[r] : 0;
+        rhi[r] = live[r] ? pd[dd][r].hi - b0[r] : 0;
+      }
 
-    cs_val pd[D][R]; /* D parent rows in flight; an index past the end of the chunk re-reads its last node */
+      /* variables that are values in the parent have been pushed there (the parent is a fixpoint);
+       * var < 0: nothing is taken for granted, every valued variable pushes */
+      u64 pushed[R], push[R], dl[R], dh[R];
 #pragma unroll
-    for (int d = 0; d < D; d++) {
-      const size_t prow = (size_t)__builtin_amdgcn_readlane(rec.parent, d < cnt ? d : cnt - 1) * n;
+      for (int r = 0; r < R; r++) {
+        pushed[r] = nvar < 0 ? ~livemask[r] : __ballot(rlo[r] == rhi[r]);
+        dl[r] = 0ull; dh[r] = 0ull;
+      }
+      /* the assignment (step_enter, csolve.c:294-304; an interval for the worker split, csolve.c:121-150) */
 #pragma unroll
-      for (int r = 0; r < R; r++) pd[d][r] = states_in[prow + vcl[r]];
-    }
+      for (int r = 0; r < R; r++) {
+        if (nvar >= 0 && (nvar >> 6) == r) {
+          const u64 bit = 1ull << (nvar & 63);
+          if (lane == (nvar & 63)) { rlo[r] = nlo - b0[r]; rhi[r] = nhi - b0[r]; }
+          pushed[r] &= ~bit;
+          if (nlo != nhi) { dl[r] |= bit; dh[r] |= bit; } /* new bounds of an open variable: to be verified */
+        }
+      }
+      int lo0[R], hi0[R];
+#pragma unroll
+      for (int r = 0; r < R; r++) { lo0[r] = rlo[r]; hi0[r] = rhi[r]; }
+      u64 val[R]; /* variables that are single values now */
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        val[r] = __ballot(rlo[r] == rhi[r]) & livemask[r];
+        push[r] = val[r] & ~pushed[r];
+      }
 
-    for (int j0 = 0; j0 < cnt; j0 += D) {
+      int rounds = 0, revisions = 0;
+      /* PUSH(u): the variable `ul` of register r is the value cd + dmin; every lane moves a bound that equals the
+       * value u forbids for it by one and is dirty then */
+      auto push_var = [&](int r, int ul, int cd) {
+        revisions += __builtin_amdgcn_readlane(deg[r], ul);
+        const E *row = s_tab + (size_t)(ul + r * CS_WAVE) * slots * W + lane;
+        u64 ml[R], mh[R]; /* lanes whose lower / upper bound is the forbidden value */
 #pragma unroll
-      for (int dd = 0; dd < D; dd++) {
-        const int j = j0 + dd;
-        if (j >= cnt) continue;
-        const int nvar = __builtin_amdgcn_readlane(rec.var, j);
-        const int nlo = __builtin_amdgcn_readlane(rec.lo, j), nhi = __builtin_amdgcn_readlane(rec.hi, j);
-        int rlo[R], rhi[R]; /* bounds relative to the root lower bound; a lane without a variable is the value 0 */
+        for (int r2 = 0; r2 < R; r2++) { ml[r2] = 0ull; mh[r2] = 0ull; }
+        if (SL != 0) {
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-          rlo[r] = live[r] ? pd[dd][r].lo - b0[r] : 0;
-          rhi[r] = live[r] ? pd[dd][r].hi - b0[r] : 0;
-        }
-        /* refill slot dd for node j + D right away: the loads fly while this node is propagated */
-        {
-          const int jn = j + D < cnt ? j + D : cnt - 1;
-          const size_t prow = (size_t)__builtin_amdgcn_readlane(rec.parent, jn) * n;
+          for (int k = 0; k < (SL ? SL : 1); k++) {
 #pragma unroll
-          for (int r = 0; r < R; r++) pd[dd][r] = states_in[prow + vcl[r]];
-        }
-
-        /* variables that are values in the parent have been pushed there (the parent is a fixpoint);
-         * var < 0: nothing is taken for granted, every valued variable pushes */
-        u64 pushed[R], push[R], dl[R], dh[R];
+            for (int r2 = 0; r2 < R; r2++) {
+              const int f = cd - (int)row[k * W + r2 * CS_WAVE]; /* the value of w that u forbids (sentinel: < 0) */
+              ml[r2] |= __ballot(f == rlo[r2]);
+              mh[r2] |= __ballot(f == rhi[r2]);
+            }
+          }
+        } else {
+          for (int k = 0; k < slots; k++) {
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-          pushed[r] = nvar < 0 ? ~livemask[r] : __ballot(rlo[r] == rhi[r]);
-          dl[r] = 0ull; dh[r] = 0ull;
-        }
-        /* the assignment (step_enter, csolve.c:294-304; an interval for the worker split, csolve.c:121-150) */
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-          if (nvar >= 0 && (nvar >> 6) == r) {
-            const u64 bit = 1ull << (nvar & 63);
-            if (lane == (nvar & 63)) { rlo[r] = nlo - b0[r]; rhi[r] = nhi - b0[r]; }
-            pushed[r] &= ~bit;
-            if (nlo != nhi) { dl[r] |= bit; dh[r] |= bit; } /* new bounds of an open variable: to be verified */
+            for (int r2 = 0; r2 < R; r2++) {
+              const int f = cd - (int)row[k * W + r2 * CS_WAVE];
+              ml[r2] |= __ballot(f == rlo[r2]);
+              mh[r2] |= __ballot(f == rhi[r2]);
+            }
           }
         }
-        int lo0[R], hi0[R];
 #pragma unroll
-        for (int r = 0; r < R; r++) { lo0[r] = rlo[r]; hi0[r] = rhi[r]; }
-        u64 val[R]; /* variables that are single values now */
-        u64 any_push = 0ull;
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-          val[r] = __ballot(rlo[r] == rhi[r]) & livemask[r];
-          push[r] = val[r] & ~pushed[r];
-          any_push |= push[r];
+        for (int r2 = 0; r2 < R; r2++) {
+          rlo[r2] += __builtin_amdgcn_inverse_ballot_w64(ml[r2]) ? 1 : 0;
+          rhi[r2] -= __builtin_amdgcn_inverse_ballot_w64(mh[r2]) ? 1 : 0;
+          dl[r2] |= ml[r2];
+          dh[r2] |= mh[r2];
         }
-
-        int rounds = 0, failed = 0, revisions = 0;
+      };
+      /* the fixpoint; returns 1 as soon as a domain is empty (no flag to carry through the loops) */
+      auto fixpoint = [&]() -> int {
         for (;;) {
-          /* (1) PUSH: every newly valued variable moves the bounds it sits on */
+          /* (1) PUSH: every newly valued variable moves the bounds it sits on.  A valued variable's bounds do
+           * not change any more, so "value - dmin" of every pusher of this round is taken from one register. */
+          int cdv[R];
+#pragma unroll
+          for (int r = 0; r < R; r++) cdv[r] = rlo[r] + kb[r];
 #pragma unroll
           for (int r = 0; r < R; r++) {
             u64 bits = push[r];
             pushed[r] |= bits;
             while (bits != 0ull) {
               const int ul = __builtin_ctzll(bits);
-              bits &= bits - 1ull;
-              const int cd = __builtin_amdgcn_readlane(rlo[r] + kb[r], ul); /* value - dmin */
-              revisions += __builtin_amdgcn_readlane(deg[r], ul);
-              const E *row = s_tab + (size_t)(ul + r * CS_WAVE) * slots * W + lane;
-              bool hl[R], hh[R];
-#pragma unroll
-              for (int r2 = 0; r2 < R; r2++) { hl[r2] = false; hh[r2] = false; }
-              if (SL != 0) {
-#pragma unroll
-                for (int k = 0; k < (SL ? SL : 1); k++) {
-#pragma unroll
-                  for (int r2 = 0; r2 < R; r2++) {
-                    const int f = cd - (int)row[k * W + r2 * CS_WAVE]; /* the value of w that u forbids (sentinel: < 0) */
-                    hl[r2] |= f == rlo[r2];
-                    hh[r2] |= f == rhi[r2];
-                  }
-                }
-              } else {
-                for (int k = 0; k < slots; k++) {
-#pragma unroll
-                  for (int r2 = 0; r2 < R; r2++) {
-                    const int f = cd - (int)row[k * W + r2 * CS_WAVE];
-                    hl[r2] |= f == rlo[r2];
-                    hh[r2] |= f == rhi[r2];
-                  }
-                }
-              }
-#pragma unroll
-              for (int r2 = 0; r2 < R; r2++) {
-                rlo[r2] += hl[r2] ? 1 : 0;
-                rhi[r2] -= hh[r2] ? 1 : 0;
-                dl[r2] |= __ballot(hl[r2]);
-                dh[r2] |= __ballot(hh[r2]);
-              }
+              bits = cs_bitset0(bits, ul);
+              push_var(r, ul, __builtin_amdgcn_readlane(cdv[r], ul));
             }
           }
-          /* (2) VERIFY: a moved bound stops at the first value no valued variable forbids */
           u64 crossed = 0ull;
 #pragma unroll
           for (int r = 0; r < R; r++) {
             crossed |= __ballot(rlo[r] > rhi[r]);
             val[r] = __ballot(rlo[r] == rhi[r]) & livemask[r];
           }
-          if (crossed != 0ull) { failed = 1; break; }
+          if (crossed != 0ull) return 1;
+          /* (2a) Many moved bounds, few valued variables (an assignment on a bound of the root domains moves a bound
+           * of every other queen): cheaper than verifying each moved bound against all valued variables is to let
+           * every valued variable push again -- each sweep moves the bounds that are still forbidden by one more
+           * value -- until the moved bounds are fewer than the valued variables. */
+          for (;;) {
+            int n_dirty = 0, n_val = 0;
 #pragma unroll
-          for (int r = 0; r < R; r++) {
-            u64 bits = dl[r] | dh[r];
-            while (bits != 0ull && !failed) {
-              const int wl = __builtin_ctzll(bits);
-              const u64 wbit = 1ull << wl;
-              bits &= ~wbit;
-              const bool do_lo = (dl[r] & wbit) != 0ull, do_hi = (dh[r] & wbit) != 0ull;
-              int cl = __builtin_amdgcn_readlane(rlo[r], wl), ch = __builtin_amdgcn_readlane(rhi[r], wl);
-              const int nkw = -__builtin_amdgcn_readlane(kb[r], wl);
-              revisions += __builtin_amdgcn_readlane(deg[r], wl);
-              const E *row = s_tab + (size_t)(wl + r * CS_WAVE) * slots * W + lane;
-              if (SL != 0) {
-                int rx[SL ? SL : 1][R]; /* the value of w that THIS lane's variable forbids when it is a value */
+            for (int r = 0; r < R; r++) { n_dirty += __popcll(dl[r] | dh[r]); n_val += __popcll(val[r]); }
+            if (n_dirty <= n_val) break;
 #pragma unroll
-                for (int k = 0; k < (SL ? SL : 1); k++)
+            for (int r = 0; r < R; r++) { cdv[r] = rlo[r] + kb[r]; dl[r] = 0ull; dh[r] = 0ull; }
 #pragma unroll
-                  for (int r2 = 0; r2 < R; r2++) rx[k][r2] = rlo[r2] + (int)row[k * W + r2 * CS_WAVE] + nkw;
-                if (do_lo) {
+            for (int r = 0; r < R; r++) {
+              u64 bits = val[r];
+              pushed[r] |= bits;
+              while (bits != 0ull) {
+                const int ul = __builtin_ctzll(bits);
+                bits = cs_bitset0(bits, ul);
+                push_var(r, ul, __builtin_amdgcn_readlane(cdv[r], ul));
+              }
+            }
+            crossed = 0ull;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+              crossed |= __ballot(rlo[r] > rhi[r]);
+              val[r] = __ballot(rlo[r] == rhi[r]) & livemask[r];
+            }
+            if (crossed != 0ull) return 1;
+          }
+          /* (2) VERIFY: a moved bound stops at the first value no valued variable forbids.  Lane u holds the
+           * table entry e of (w, k, u); its own value forbids the value rlo[u] + e - kb[w] of w, i.e. the
+           * candidate c is forbidden iff e == c + kb[w] - rlo[u]: one subtraction per register, the compares run
+           * on the raw table bytes.  Mostly the candidate is supported and nothing is written. */
+#pragma unroll
+          for (int side = 0; side < 2; side++) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+              u64 bits = side == 0 ? dl[r] : dh[r];
+              if (side == 0) dl[r] = 0ull; else dh[r] = 0ull;
+              while (bits != 0ull) {
+                const int wl = __builtin_ctzll(bits);
+                bits = cs_bitset0(bits, wl);
+                int cand = __builtin_amdgcn_readlane(side == 0 ? rlo[r] : rhi[r], wl);
+                const int ckw = cand + __builtin_amdgcn_readlane(kb[r], wl);
+                revisions += __builtin_amdgcn_readlane(deg[r], wl);
+                const E *row = s_tab + (size_t)(wl + r * CS_WAVE) * slots * W + lane;
+                u64 hit = 0ull;
+                if (SL != 0) {
+                  int e[SL ? SL : 1][R];
+#pragma unroll
+                  for (int k = 0; k < (SL ? SL : 1); k++)
+#pragma unroll
+                    for (int r2 = 0; r2 < R; r2++) e[k][r2] = (int)row[k * W + r2 * CS_WAVE];
+#pragma unroll
+                  for (int r2 = 0; r2 < R; r2++) {
+                    const int t = ckw - rlo[r2];
+                    u64 h = 0ull;
+#pragma unroll
+                    for (int k = 0; k < (SL ? SL : 1); k++) h |= __ballot(e[k][r2] == t);
+                    hit |= h & val[r2];
+                  }
+                  if (hit == 0ull) continue; /* supported: the common case */
+                  /* the bound moves on, one value (one PROPS) at a time, until it is supported or passes the other */
+                  const int other = __builtin_amdgcn_readlane(side == 0 ? rhi[r] : rlo[r], wl);
+                  int step = 0;
                   for (;;) {
-                    u64 hit = 0ull;
+                    step++;
+                    if (side == 0 ? cand + step > other : cand - step < other) break;
+                    hit = 0ull;
 #pragma unroll
                     for (int r2 = 0; r2 < R; r2++) {
-                      bool h = false;
+                      const int t = ckw + (side == 0 ? step : -step) - rlo[r2];
+                      u64 h = 0ull;
 #pragma unroll
-                      for (int k = 0; k < (SL ? SL : 1); k++) h |= rx[k][r2] == cl;
-                      hit |= __ballot(h) & val[r2];
+                      for (int k = 0; k < (SL ? SL : 1); k++) h |= __ballot(e[k][r2] == t);
+                      hit |= h & val[r2];
                     }
                     if (hit == 0ull) break;
-                    cl++;
-                    if (cl > ch) break;
                   }
-                }
-                if (do_hi && cl <= ch) {
+                  cand += side == 0 ? step : -step;
+                  if (lane == wl) { if (side == 0) rlo[r] = cand; else rhi[r] = cand; }
+                  /* a bound that passed the other one is the failure: noticed after the loops (no exit from in here) */
+                  crossed |= (side == 0 ? cand > other : cand < other) ? 1ull : 0ull;
+                  if (cand == other) val[r] |= 1ull << wl; /* counts for the verifications that follow */
+                } else {
+                  /* run-time slot count: the row is re-read per candidate */
+                  const int other = __builtin_amdgcn_readlane(side == 0 ? rhi[r] : rlo[r], wl);
+                  int step = 0;
                   for (;;) {
-                    u64 hit = 0ull;
-#pragma unroll
-                    for (int r2 = 0; r2 < R; r2++) {
-                      bool h = false;
-#pragma unroll
-                      for (int k = 0; k < (SL ? SL : 1); k++) h |= rx[k][r2] == ch;
-                      hit |= __ballot(h) & val[r2];
-                    }
-                    if (hit == 0ull) break;
-                    ch--;
-                    if (cl > ch) break;
-                  }
-                }
-              } else {
-                /* run-time slot count: one candidate at a time, the row re-read per candidate */
-                for (int side = 0; side < 2; side++) {
-                  if (side == 0 ? !do_lo : (!do_hi || cl > ch)) continue;
-                  for (;;) {
-                    const int cand = side == 0 ? cl : ch;
-                    u64 hit = 0ull;
+                    hit = 0ull;
                     for (int k = 0; k < slots; k++) {
 #pragma unroll
                       for (int r2 = 0; r2 < R; r2++)
-                        hit |= __ballot(rlo[r2] + (int)row[k * W + r2 * CS_WAVE] + nkw == cand) & val[r2];
+                        hit |= __ballot((int)row[k * W + r2 * CS_WAVE] == ckw + (side == 0 ? step : -step) - rlo[r2]) & val[r2];
                     }
                     if (hit == 0ull) break;
-                    if (side == 0) cl++; else ch--;
-                    if (cl > ch) break;
+                    step++;
+                    if (side == 0 ? cand + step > other : cand - step < other) break;
+                  }
+                  if (step != 0) {
+                    cand += side == 0 ? step : -step;
+                    if (lane == wl) { if (side == 0) rlo[r] = cand; else rhi[r] = cand; }
+                    crossed |= (side == 0 ? cand > other : cand < other) ? 1ull : 0ull;
+                    if (cand == other) val[r] |= 1ull << wl;
                   }
                 }
               }
-              if (lane == wl) { rlo[r] = cl; rhi[r] = ch; }
-              if (cl > ch) failed = 1;
-              else if (cl == ch) val[r] |= wbit; /* counts for the verifications that follow */
             }
-            dl[r] = 0ull; dh[r] = 0ull;
           }
-          if (failed) break;
+          if (crossed != 0ull) return 1;
           /* (3) variables that became values (and are supported) push next */
-          any_push = 0ull;
+          u64 any_push = 0ull;
 #pragma unroll
           for (int r = 0; r < R; r++) {
             push[r] = val[r] & ~pushed[r];
             any_push |= push[r];
           }
-          if (any_push == 0ull) break;
+          if (any_push == 0ull) return 0;
+          /* a node that goes on cascading is a candidate for the tail of the launch (a few nodes cost 50 times the
+           * average): from its second round on its wave is served first by the SIMD's arbiter */
+          if (rounds == 0) __builtin_amdgcn_s_setprio(3);
           rounds++;
         }
+      };
+      const int failed = fixpoint();
+      if (rounds != 0) __builtin_amdgcn_s_setprio(0);
 
-        int open_vars = 0, shaved = 0;
+      int open_vars = 0, shaved = 0;
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-          open_vars += __popcll(__ballot(rlo[r] != rhi[r]));
-          shaved += (rlo[r] - lo0[r]) + (hi0[r] - rhi[r]);
-        }
-        const int props = cs_wave_sum(shaved);
-        const size_t orow = (size_t)(base + j) * n;
-        if (FULL) {
-#pragma unroll
-          for (int r = 0; r < R; r++) states_out[orow + lane + r * CS_WAVE] = cs_interval(rlo[r] + b0[r], rhi[r] + b0[r]);
-        } else if (!failed) {
-#pragma unroll
-          for (int r = 0; r < R; r++)
-            if (live[r]) states_out[orow + lane + r * CS_WAVE] = cs_interval(rlo[r] + b0[r], rhi[r] + b0[r]);
-        }
-        if (lane == j) {
-          my_result.status = failed ? -1 : open_vars;
-          my_result.props = props;
-          my_result.revisions = revisions;
-          my_result.rounds = rounds;
-        }
+      for (int r = 0; r < R; r++) {
+        open_vars += __popcll(__ballot(rlo[r] != rhi[r]));
+        shaved += (rlo[r] - lo0[r]) + (hi0[r] - rhi[r]);
       }
+      const int props = cs_wave_sum(shaved);
+      const size_t orow = (size_t)(base + j) * n;
+      if (FULL) {
+#pragma unroll
+        for (int r = 0; r < R; r++) states_out[orow + lane + r * CS_WAVE] = cs_interval(rlo[r] + b0[r], rhi[r] + b0[r]);
+      } else if (!failed) {
+#pragma unroll
+        for (int r = 0; r < R; r++)
+          if (live[r]) states_out[orow + lane + r * CS_WAVE] = cs_interval(rlo[r] + b0[r], rhi[r] + b0[r]);
+      }
+      my_result.status = __builtin_amdgcn_writelane(failed ? -1 : open_vars, j, my_result.status);
+      my_result.props = __builtin_amdgcn_writelane(props, j, my_result.props);
+      my_result.revisions = __builtin_amdgcn_writelane(revisions, j, my_result.revisions);
+      my_result.rounds = __builtin_amdgcn_writelane(rounds, j, my_result.rounds);
     }
     if (lane < cnt) results[base + lane] = my_result;
+
+    if (!have_next) break;
+    /* step the pipeline: the next chunk becomes the current one, the ticket drawn above names the one after */
+    const int i_nn = next_index(i_next, tk);
+    const int have_nn = i_nn < count_x;
+    i_cur = i_next;
+    rec_cur = rec_next;
+#pragma unroll
+    for (int d = 0; d < D; d++)
+#pragma unroll
+      for (int r = 0; r < R; r++) pd[d][r] = pn[d][r];
+    rec_next = load_rec(have_nn ? i_nn : i_next);
+    i_next = i_nn;
+    have_next = have_nn;
   }
+#ifdef CS_SHAVE_TIMELINE
+  if (lane == 0) {
+    const size_t w = ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) % 65536;
+    cs_shave_tl[3 * w] = tl_start;
+    cs_shave_tl[3 * w + 1] = __builtin_amdgcn_s_memrealtime();
+    cs_shave_tl[3 * w + 2] = tl_nodes;
+  }
+#endif
 }
 
 #endif

@@ -11,6 +11,7 @@
  *                             also with the states carried as the sets alone
  *   cs_propagate_ne_packed(5) kernel 4 for at most 32 variables: two or four nodes per wave
  *   cs_propagate_clause_rounds (6) at most 512 clauses, resident in registers: all revised per round
+ *   cs_propagate_ne_shave (7, cs_shave.hip.h) kernel 4's models on interval states alone: the bench kernel
  *   cs_propagate_sweeps, cs_eval_root, cs_eval_clauses, cs_sets_unpack: root phase, evaluation, layout helper
  *
  * Execution model of the general kernel (cs_propagate_events):

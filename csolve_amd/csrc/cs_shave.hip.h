@@ -428,10 +428,12 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_shave(
         for (int r = 0; r < R; r++)
           if (live[r]) states_out[orow + lane + r * CS_WAVE] = cs_interval(rlo[r] + b0[r], rhi[r] + b0[r]);
       }
-      my_result.status = __builtin_amdgcn_writelane(failed ? -1 : open_vars, j, my_result.status);
-      my_result.props = __builtin_amdgcn_writelane(props, j, my_result.props);
-      my_result.revisions = __builtin_amdgcn_writelane(revisions, j, my_result.revisions);
-      my_result.rounds = __builtin_amdgcn_writelane(rounds, j, my_result.rounds);
+      if (lane == j) {
+        my_result.status = failed ? -1 : open_vars;
+        my_result.props = props;
+        my_result.revisions = revisions;
+        my_result.rounds = rounds;
+      }
     }
     if (lane < cnt) results[base + lane] = my_result;
 

@@ -129,8 +129,8 @@ class Model:
 
     def set_kernel(self, which: int):
         """0 automatic, 1 general kernel, 2 LDS-resident unit shaving, 3 forbidden sets in LDS,
-        4 forbidden sets in registers, 5 the same with two or four nodes per wave (2-5: pure binary-NE
-        models that fit, see csolve_gpu.h)"""
+        4 forbidden sets in registers, 5 the same with two or four nodes per wave, 6 clause-resident (small
+        models), 7 interval-only shaving (2-5, 7: pure binary-NE models that fit, see csolve_gpu.h)"""
         check(load_library().csgpu_model_set_kernel(self._h, which))
         return self
 

@@ -138,13 +138,15 @@ int csgpu_propagate_batch_sets(const csgpu_model *m, const uint64_t *d_sets_in, 
  * at most 256 variables and a dense pair table that fits in LDS), 5 = kernel 4 with two or four
  * nodes per wavefront (additionally at most 32 variables of at most 64 values; 4 then means one
  * node per wavefront), 6 = the clause-resident kernel for small models (at most 512 clauses: every
- * lane keeps its clauses in registers and a round revises all of them); CSGPU_E_LIMIT if the model does not qualify.  All compute the same
- * results; tests run every parity case through each of them.
- * Automatic: csgpu_propagate_batch_fb uses 5 when the model qualifies, else 4, else 3;
- * csgpu_propagate_batch (no sets passed) uses 5, 4 or 3 with the sets rebuilt from the incoming state
- * when the model qualifies (3.7x / 8x faster than 2 on queens-64 / queens-16), else 2, else 6 (at most 256
- * clauses; with 257-512 for batches of at most 8192 nodes only, where its lower latency counts and its
- * lower throughput does not), else 1. */
+ * lane keeps its clauses in registers and a round revises all of them), 7 = the interval-only shaving
+ * kernel (models that qualify for 4: bounds are shaved by pushes and moved bounds verified against the
+ * valued variables through the symmetric pair table; no forbidden sets anywhere);
+ * CSGPU_E_LIMIT if the model does not qualify.  All compute the same results; tests run every parity
+ * case through each of them.
+ * Automatic: csgpu_propagate_batch_fb (sets passed) uses 5 when the model qualifies, else 4, else 3;
+ * csgpu_propagate_batch (states only) uses 5 with the sets rebuilt for models of at most 32 variables,
+ * else 7, else 3 with the sets rebuilt, else 2, else 6 (at most 256 clauses; with 257-512 for batches of
+ * at most 8192 nodes only, where its lower latency counts and its lower throughput does not), else 1. */
 int csgpu_model_set_kernel(csgpu_model *m, int which);
 /* Process-wide switch for models finalized afterwards: 1 (default) = EQ / LT / two-literal OR clauses
  * over `VAR` or `VAR + constant` operands are revised by direct bound propagation (schedule.txt-style

@@ -418,6 +418,9 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args, text, model, legs["states_in"], legs["nodes"], head["states_out"], res_h)
         if not (args.sudoku or args.schedule) and n_q == 64 and not args.no_queens128:
             out["queens128"] = queens128_record(args)
+            e2e = end_to_end_record()
+            if e2e is not None:
+                out["end_to_end"] = e2e
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
@@ -574,6 +577,47 @@ def leg_summary(leg):
             "frac_of_hbm_peak_on_necessary_bytes": (16 * n + 32) * B / t / 1e9 / HBM_PEAK_GBS,
             "frac_of_hbm_peak_on_layout_bytes": leg["layout_bytes"] / t / 1e9 / HBM_PEAK_GBS,
             "layout_bytes_per_node": leg["layout_bytes"] / B}
+
+
+def end_to_end_record():
+    """The north-star scenario as a whole: the reference's own search driver (csolve.c, strategy.c, ... compiled from the
+    reference's sources) with its default heuristics (only conflict learning off), once with the reference's CPU
+    propagator and once linked against libcsolve_dropin.so (every propagate / propagate_clauses / eval on the GPU),
+    on queens-64 and queens-128, same box.  The two searches are both valid but not call for call the same: the
+    reference's failure chains (propagate.c:44-54) depend on its revision order."""
+    import re
+    import subprocess
+    import tempfile
+    dropin = os.path.join(ROOT, "oracle", "_ref", "csolve_ref_dropin")
+    if not (os.path.exists(REF_BIN) and os.path.exists(dropin)):
+        return None
+    out = {}
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        for nq in (64, 128):
+            prob = os.path.join(tmp, f"queens{nq}.txt")
+            open(prob, "w").write(problems.queens(nq))
+            rec = {}
+            for name, binary in (("cpu_reference", REF_BIN), ("reference_driver_on_gpu_propagator", dropin)):
+                p = subprocess.run([binary, "solve", prob, "-c", "false"], capture_output=True, text=True, timeout=600)
+                if p.returncode != 0:
+                    return {"error": p.stderr[-300:]}
+                st = json.loads(re.search(r"@STATS (\{.*\})", p.stdout).group(1))
+                r = {k: st[k] for k in ("calls", "cuts", "props", "restarts", "solutions", "solve_seconds", "root_seconds")}
+                m = re.search(r"@DROPIN (\{.*\})", p.stdout)
+                if m:
+                    d = json.loads(m.group(1))
+                    r["device_call_seconds"] = d["device_call_seconds"]
+                    r["shim_host_seconds"] = d["shim_host_seconds"]
+                    r["attach_seconds"] = d["attach_seconds"]
+                r["us_per_call"] = 1e6 * st["solve_seconds"] / max(1, st["calls"])
+                rec[name] = r
+            rec["solve_speedup"] = rec["cpu_reference"]["solve_seconds"] / rec["reference_driver_on_gpu_propagator"]["solve_seconds"]
+            rec["per_call_speedup"] = rec["cpu_reference"]["us_per_call"] / rec["reference_driver_on_gpu_propagator"]["us_per_call"]
+            out[f"queens{nq}"] = rec
+    out["flags"] = "-c false (defaults otherwise: -f true -r 100 -o none)"
+    out["note"] = ("solve_seconds = the reference's solve() only; root_seconds (parse + root phase; on the GPU build it "
+                   "contains the HIP start-up) is listed separately")
+    return out
 
 
 def queens128_record(args):

@@ -111,6 +111,8 @@ def load_library():
     L.csgpu_search_best_solution.argtypes = [vp, vp]
     L.csgpu_search_solutions.restype = i64
     L.csgpu_propagate_one.argtypes = [vp, vp, Node, vp, C.POINTER(Result)]
+    L.csgpu_propagate_values.argtypes = [vp, vp, i32, vp, i32, vp, vp]
+    L.csgpu_model_root_propagate_limit.argtypes = [vp, i64, C.POINTER(i32), C.POINTER(i32)]
     _lib = L
     return L
 

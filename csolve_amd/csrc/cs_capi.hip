@@ -84,6 +84,9 @@ struct csgpu_model {
   cs_val *d_one_in, *d_one_out;  /* device views of the four parts */
   cs_node_in *d_one_node;
   cs_node_out *d_one_res;
+  /* staging of csgpu_propagate_values (mapped pinned memory, grown on demand) */
+  unsigned char *h_values, *d_values;
+  size_t values_cap;
 };
 
 extern "C" const char *csgpu_last_error(void) { return g_err; }
@@ -184,6 +187,9 @@ static void free_device(csgpu_model *m) {
   m->fb_words = 0;
   (void)hipHostFree(m->h_one);
   m->h_one = NULL;
+  if (m->h_values != NULL) (void)hipHostFree(m->h_values);
+  m->h_values = m->d_values = NULL;
+  m->values_cap = 0;
   m->d_adj_off = m->d_adj = m->d_clause = m->d_tree_off = m->d_tnode = m->d_tkid = NULL;
   m->d_one_in = m->d_one_out = NULL;
   m->d_one_node = NULL;
@@ -301,6 +307,10 @@ static int lds_limit(size_t bytes, const void *func) {
 /* ---- root phase -------------------------------------------------------------------- */
 
 extern "C" int csgpu_model_root_propagate(csgpu_model *m, int32_t *status) {
+  return csgpu_model_root_propagate_limit(m, -1, status, NULL);
+}
+
+extern "C" int csgpu_model_root_propagate_limit(csgpu_model *m, int64_t limit, int32_t *status, int32_t *rounds) {
   if (m == NULL || status == NULL) return set_err(CSGPU_E_ARG, "null argument");
   cs_model *h = m->host;
   if (h->root < 0) return set_err(CSGPU_E_STATE, "model has no root");
@@ -326,13 +336,17 @@ extern "C" int csgpu_model_root_propagate(csgpu_model *m, int32_t *status) {
       rc = set_err(CSGPU_E_HIP, "root propagate setup: %s", hipGetErrorString(e));
   }
   if (rc == CSGPU_OK) {
-    hipLaunchKernelGGL(cs_propagate_sweeps, dim3(1), dim3(CS_BLOCK), lds, 0, tab, d_in, d_out, d_res, 0x7fffffff);
+    /* propagate(root, limit) stops after limit + 1 sweeps (propagate.c:479-483) */
+    const int max_rounds = limit < 0 || limit >= 0x7ffffffe ? 0x7fffffff : (int)limit + 1;
+    hipLaunchKernelGGL(cs_propagate_sweeps, dim3(1), dim3(CS_BLOCK), lds, 0, tab, d_in, d_out, d_res, max_rounds);
     if ((e = hipGetLastError()) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess ||
         (e = hipMemcpy(&res, d_res, sizeof res, hipMemcpyDeviceToHost)) != hipSuccess ||
         (e = hipMemcpy(h->dom, d_out, (size_t)h->n_vars * sizeof(cs_val), hipMemcpyDeviceToHost)) != hipSuccess)
       rc = set_err(CSGPU_E_HIP, "root propagate: %s", hipGetErrorString(e));
-    else
+    else {
       *status = res.status < 0 ? -1 : res.props;
+      if (rounds != NULL) *rounds = res.rounds;
+    }
   }
   (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_res);
   free_tables(&own);
@@ -1191,6 +1205,43 @@ extern "C" int csgpu_eval_clauses(const csgpu_model *m, const csgpu_val *d_state
   hipLaunchKernelGGL(cs_eval_clauses, dim3(blocks), dim3(CS_BLOCK), lds, (hipStream_t)stream, m->tab,
                      (const cs_val *)d_state, (cs_val *)d_vals);
   HIP_TRY(hipGetLastError());
+  return CSGPU_OK;
+}
+
+/* `count` values of one variable on one parent state, host buffers: the sibling batch of the drop-in shim (the
+ * driver tries them one after the other, csolve.c:331-338; the device takes them at once).  The parent, the node
+ * records, the results and the new states live in mapped pinned memory: one launch, one wait. */
+extern "C" int csgpu_propagate_values(const csgpu_model *cm, const csgpu_val *state, int32_t var, const int32_t *values,
+                                      int32_t count, csgpu_val *states_out, csgpu_result *results) {
+  csgpu_model *m = (csgpu_model *)cm;
+  if (m == NULL || state == NULL || values == NULL || states_out == NULL || results == NULL)
+    return set_err(CSGPU_E_ARG, "null argument");
+  if (!m->finalized) return set_err(CSGPU_E_STATE, "model is not finalized");
+  const int n = m->host->n_vars;
+  if (var < 0 || var >= n || count < 0 || count > (1 << 20)) return set_err(CSGPU_E_ARG, "bad argument");
+  if (count == 0) return CSGPU_OK;
+  const size_t row = (size_t)n * sizeof(cs_val);
+  const size_t off_nodes = (row + 255) & ~(size_t)255;
+  const size_t off_res = off_nodes + (((size_t)count * sizeof(cs_node_in) + 255) & ~(size_t)255);
+  const size_t off_out = off_res + (((size_t)count * sizeof(cs_node_out) + 255) & ~(size_t)255);
+  const size_t need = off_out + (size_t)count * row;
+  if (need > m->values_cap) {
+    if (m->h_values != NULL) (void)hipHostFree(m->h_values);
+    m->h_values = NULL;
+    m->values_cap = 0;
+    HIP_TRY(hipHostMalloc((void **)&m->h_values, need * 2, hipHostMallocMapped));
+    HIP_TRY(hipHostGetDevicePointer((void **)&m->d_values, m->h_values, 0));
+    m->values_cap = need * 2;
+  }
+  memcpy(m->h_values, state, row);
+  cs_node_in *nd = (cs_node_in *)(m->h_values + off_nodes);
+  for (int32_t i = 0; i < count; i++) { nd[i].var = var; nd[i].lo = nd[i].hi = values[i]; nd[i].parent = 0; }
+  int rc = csgpu_propagate_batch(m, (const csgpu_val *)m->d_values, (const csgpu_node *)(m->d_values + off_nodes),
+                                 (csgpu_val *)(m->d_values + off_out), (csgpu_result *)(m->d_values + off_res), count, NULL);
+  if (rc != CSGPU_OK) return rc;
+  HIP_TRY(hipStreamSynchronize(NULL));
+  memcpy(results, m->h_values + off_res, (size_t)count * sizeof *results);
+  memcpy(states_out, m->h_values + off_out, (size_t)count * row);
   return CSGPU_OK;
 }
 

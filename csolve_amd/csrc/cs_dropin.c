@@ -8,20 +8,31 @@
  *     unbind(step->bind_depth) restores the parent state (reference src/csolve.c:309);
  *   - the driver's `props` statistic is advanced by the number of narrowings;
  *   - conflict_reset() at the entry of propagate_clauses (reference src/propagate.c:496).
- * Not reproduced: prio++/strategy_var_order_update of the failing variable (heuristic only;
- * the deterministic mode -f false is unaffected), conflict-clause creation (run the driver
- * with -c false), the in-search normalise/patch tail.
+ *   - on inconsistency the variable whose domain emptied gets prio++ and strategy_var_order_update()
+ *     (propagate_term_confl, reference src/propagate.c:33-41): the device reports one such variable.  The
+ *     reference additionally bumps every variable on its recursion stack (propagate.c:44-54); that stack is
+ *     a property of its depth-first revision order and has no counterpart here, so default-flag (-f true)
+ *     runs are valid searches but not call-for-call the reference's; -f false runs are.
+ *   - propagate(root, limit): at most limit + 1 device sweeps (csgpu_model_root_propagate_limit).
+ * Sibling batching (CSOLVE_DROPIN_SIBLINGS=1): the driver tries the values of a variable one after the other
+ * (step_val, csolve.c:331-338), each through bind + propagate_clauses.  The first such call propagates the next
+ * two values in the driver's order in one launch (csgpu_propagate_values), later ones twice as many; calls are
+ * served from the batch as long as the other variables' domains are what they were (checked on every call).
+ * Same search, call for call; off by default because it does not pay on the driver's depth-first descent.
+ * Not reproduced: conflict-clause creation (run the driver with -c false), the in-search normalise/patch tail.
  */
 #include "../../include/csolve_dropin.h"
 
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "cs_internal.h"
 
 /* ---- provided by the reference driver ------------------------------------------------ */
 extern void bind(struct env_t *var, struct val_t val, const struct wand_expr_t *clause);
+extern void strategy_var_order_update(struct env_t *e);
 extern void conflict_reset(void);
 extern void print_fatal(const char *fmt, ...);
 extern uint64_t props;
@@ -186,8 +197,63 @@ static int g_trace = -1;           /* CSOLVE_DROPIN_TRACE=1: entry points on std
 #define TRACE(...) do { if (g_trace < 0) g_trace = getenv("CSOLVE_DROPIN_TRACE") != NULL; if (g_trace) { fprintf(stderr, __VA_ARGS__); fflush(stderr); } } while (0)
 static csgpu_val *g_state, *g_out;
 static uint64_t g_calls[4];
+static uint64_t g_sib_launches, g_sib_served; /* sibling batches launched, calls served from one */
+
+/* layout of the driver's trail entry (reference src/csolve.h:73-79): env_t.binds points at the newest one */
+struct binding_view {
+  struct env_t *var;
+  struct val_t val; /* the variable's value BEFORE the bind */
+  size_t level;
+  const struct wand_expr_t *clause;
+  struct binding_view *prev;
+};
+
+/* the last sibling batch: the next `count` values of `var` in the driver's order (step_val, csolve.c:331-338:
+ * from the edges of the interval inwards, alternating) on the parent `parent` (var's own slot is ignored).  The
+ * first batch of a (variable, parent) holds two values, every further one twice as many: a launch takes as long as
+ * its slowest node, and the driver usually descends after one or two values. */
+static struct {
+  int valid, var, lo, hi; /* the interval being iterated */
+  int first_is_lo;        /* the driver's seed parity: value 0 of the iteration is lo (else hi) */
+  int next_iter;          /* iteration index of the first value NOT in a batch yet */
+  int count;              /* values in this batch */
+  int32_t *values;
+  csgpu_val *parent, *outs;
+  csgpu_result *res;
+  size_t cap_rows;
+} g_sib;
+#define CS_SIBLING_MAX 4096
+
+void csolve_dropin_sibling_counters(uint64_t out[2]) { out[0] = g_sib_launches; out[1] = g_sib_served; }
+
+/* where the shim's time goes: [0] attach (flatten + finalize + upload), [1] inside the device calls of
+ * propagate_clauses, [2] the rest of propagate_clauses (state marshalling, bind() replay) */
+static double g_seconds[3];
+static double now_s(void) {
+  struct timespec t;
+  clock_gettime(CLOCK_MONOTONIC, &t);
+  return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+}
+void csolve_dropin_seconds(double out[3]) { memcpy(out, g_seconds, sizeof g_seconds); }
 
 static void fatal_gpu(const char *what) { print_fatal("%s: %s", what, csgpu_last_error()); }
+
+/* Values of expression nodes, valid while no domain changes: the driver's normalize() (normalize.c:67-75,
+ * 305-316) asks for the value of every node of the root tree, one eval_<op> call per node, between the two root
+ * propagations.  The first such call evaluates EVERY node below the last root on the device in one launch; nodes
+ * that normalisation creates afterwards are evaluated (with everything below them) when they are asked for.
+ * Dropped at every entry point that can change a domain. */
+static pmap g_eval_cache;          /* constr_t* -> index into g_eval_vals */
+static csgpu_val *g_eval_vals;
+static size_t g_eval_n, g_eval_cap;
+static int g_eval_root_done;
+static uint64_t g_eval_launches;
+
+static void eval_cache_drop(void) {
+  if (g_eval_cache.key != NULL) pmap_free(&g_eval_cache);
+  g_eval_n = 0;
+  g_eval_root_done = 0;
+}
 
 void csolve_dropin_counters(uint64_t out[4]) { memcpy(out, g_calls, sizeof g_calls); }
 
@@ -197,12 +263,16 @@ void csolve_dropin_detach(void) {
   free(g_state);
   free(g_out);
   g_state = g_out = NULL;
+  free(g_sib.parent); free(g_sib.outs); free(g_sib.res); free(g_sib.values);
+  memset(&g_sib, 0, sizeof g_sib);
   g_env = NULL;
   g_size = 0;
 }
 
 static int attach(struct env_t *env, size_t size, struct constr_t *root, int at_root) {
   TRACE("[dropin] attach size=%zu at_root=%d\n", size, at_root);
+  const double t_attach = now_s();
+  eval_cache_drop();
   csolve_dropin_detach();
   flat f;
   memset(&f, 0, sizeof f);
@@ -250,6 +320,7 @@ static int attach(struct env_t *env, size_t size, struct constr_t *root, int at_
   g_state = (csgpu_val *)malloc((size ? size : 1) * sizeof *g_state);
   g_out = (csgpu_val *)malloc((size ? size : 1) * sizeof *g_out);
   TRACE("[dropin] attached\n");
+  g_seconds[0] += now_s() - t_attach;
   return 0;
 }
 
@@ -302,9 +373,42 @@ domain_t max(domain_t a, domain_t b) { return cs_max(a, b); }
 
 /* ---- propagate_clauses ------------------------------------------------------------------------ */
 
+/* what the device found for one node, handed to the driver: trail, PROPS, failure side effects */
+static prop_result_t deliver(int32_t var, const csgpu_result *res, const csgpu_val *out) {
+  props += (uint64_t)res->props; /* narrowings of an inconsistent node count too (propagate.c:78) */
+  if (res->status < 0) {
+    /* propagate_term_confl (propagate.c:33-41): the variable whose domain emptied */
+    const int32_t fv = res->rounds;
+    if (fv >= 0 && (size_t)fv < g_size) {
+      /* (bumping it once more per narrowing it had received in the node -- one recursion frame of the reference
+       * each -- was tried and derails the heuristic: queens-32 .. 128 then need 150,000+ calls instead of 1,000 ..
+       * 4,000) */
+      g_env[fv].prio++;
+      strategy_var_order_update(&g_env[fv]);
+    }
+    return PROP_ERROR;
+  }
+  for (size_t i = 0; i < g_size; i++)
+    if (out[i].lo != g_state[i].lo || out[i].hi != g_state[i].hi) {
+      struct val_t v = { out[i].lo, out[i].hi };
+      bind(&g_env[i], v, NULL);
+    }
+  (void)var;
+  return res->props;
+}
+
+static prop_result_t propagate_clauses_timed(const struct clause_list_t *clauses);
 prop_result_t propagate_clauses(const struct clause_list_t *clauses) {
+  eval_cache_drop();
   conflict_reset();
   if (g_model == NULL) lazy_attach(clauses);
+  const double t0 = now_s(), dev0 = g_seconds[1];
+  const prop_result_t r = propagate_clauses_timed(clauses);
+  g_seconds[2] += (now_s() - t0) - (g_seconds[1] - dev0);
+  return r;
+}
+
+static prop_result_t propagate_clauses_timed(const struct clause_list_t *clauses) {
   struct env_t *owner = (struct env_t *)((char *)clauses - offsetof(struct env_t, clauses));
   if (owner < g_env || owner >= g_env + g_size) print_fatal("propagate_clauses: list of an unknown variable");
   const int32_t var = (int32_t)(owner - g_env);
@@ -312,20 +416,81 @@ prop_result_t propagate_clauses(const struct clause_list_t *clauses) {
     g_state[i].lo = g_env[i].val->constr.term.val.lo;
     g_state[i].hi = g_env[i].val->constr.term.val.hi;
   }
+  g_calls[0]++;
+  static int batching = -1;
+  /* opt-in: a batch takes as long as its slowest node, and the reference's driver usually descends after the first
+   * value, so on its depth-first searches speculation costs more than it saves */
+  if (batching < 0) batching = getenv("CSOLVE_DROPIN_SIBLINGS") != NULL && atoi(getenv("CSOLVE_DROPIN_SIBLINGS")) != 0;
+  const int32_t k = g_state[var].lo;
+  if (batching && g_state[var].lo == g_state[var].hi) {
+    /* the iteration this call belongs to: same variable, every OTHER domain what it was */
+    int same = g_sib.valid && g_sib.var == var && k >= g_sib.lo && k <= g_sib.hi;
+    for (size_t i = 0; i < g_size && same; i++)
+      same = (int32_t)i == var || (g_sib.parent[i].lo == g_state[i].lo && g_sib.parent[i].hi == g_state[i].hi);
+    if (same) {
+      for (int j = 0; j < g_sib.count; j++)
+        if (g_sib.values[j] == k) {
+          g_sib_served++;
+          TRACE("[dropin] propagate_clauses var=%d value %d: from the sibling batch\n", var, k);
+          return deliver(var, &g_sib.res[j], g_sib.outs + (size_t)j * g_size);
+        }
+    } else {
+      /* a new iteration: the interval = the variable's value before step_enter's bind (csolve.c:294-304) */
+      const struct binding_view *b = (const struct binding_view *)owner->binds;
+      g_sib.valid = 0;
+      if (b != NULL && b->var == owner && b->val.lo < b->val.hi && (k == b->val.lo || k == b->val.hi) &&
+          (int64_t)b->val.hi - b->val.lo < CS_SIBLING_MAX) {
+        if (g_sib.parent == NULL) g_sib.parent = (csgpu_val *)malloc((g_size ? g_size : 1) * sizeof(csgpu_val));
+        memcpy(g_sib.parent, g_state, g_size * sizeof(csgpu_val));
+        g_sib.valid = 1; g_sib.var = var; g_sib.lo = b->val.lo; g_sib.hi = b->val.hi;
+        g_sib.first_is_lo = k == b->val.lo;
+        g_sib.next_iter = 0;
+        g_sib.count = 0;
+      }
+    }
+    if (g_sib.valid) {
+      /* the next values in the driver's order, starting with the one asked for now */
+      const int width = g_sib.hi - g_sib.lo + 1;
+      int want = g_sib.count == 0 ? 2 : 2 * g_sib.count;
+      if (want > width - g_sib.next_iter) want = width - g_sib.next_iter;
+      if ((size_t)want > g_sib.cap_rows) {
+        free(g_sib.outs); free(g_sib.res); free(g_sib.values);
+        g_sib.cap_rows = (size_t)want * 2;
+        g_sib.outs = (csgpu_val *)malloc(g_sib.cap_rows * (g_size ? g_size : 1) * sizeof(csgpu_val));
+        g_sib.res = (csgpu_result *)malloc(g_sib.cap_rows * sizeof(csgpu_result));
+        g_sib.values = (int32_t *)malloc(g_sib.cap_rows * sizeof(int32_t));
+      }
+      int found = -1;
+      for (int j = 0; j < want; j++) {
+        const int it = g_sib.next_iter + j;
+        const int from_lo = ((it & 1) == 0) == (g_sib.first_is_lo != 0);
+        g_sib.values[j] = from_lo ? g_sib.lo + (it >> 1) : g_sib.hi - (it >> 1);
+        if (g_sib.values[j] == k) found = j;
+      }
+      if (found >= 0) {
+        g_sib.parent[var].lo = g_sib.lo;
+        g_sib.parent[var].hi = g_sib.hi;
+        TRACE("[dropin] propagate_clauses var=%d: sibling batch of %d from value %d\n", var, want, k);
+        const double td = now_s();
+        if (csgpu_propagate_values(g_model, g_sib.parent, var, g_sib.values, want, g_sib.outs, g_sib.res) != CSGPU_OK)
+          fatal_gpu("propagate_clauses");
+        g_seconds[1] += now_s() - td;
+        g_sib.count = want;
+        g_sib.next_iter += want;
+        g_sib_launches++;
+        return deliver(var, &g_sib.res[found], g_sib.outs + (size_t)found * g_size);
+      }
+      g_sib.valid = 0; /* not the order this shim predicts: single nodes from here on */
+    }
+  }
   csgpu_node node = { var, g_state[var].lo, g_state[var].hi, 0 };
   csgpu_result res;
-  g_calls[0]++;
   TRACE("[dropin] propagate_clauses var=%d [%d,%d]\n", node.var, node.lo, node.hi);
+  const double td = now_s();
   if (csgpu_propagate_one(g_model, g_state, node, g_out, &res) != CSGPU_OK) fatal_gpu("propagate_clauses");
+  g_seconds[1] += now_s() - td;
   TRACE("[dropin]   -> status %d props %d rounds %d\n", res.status, res.props, res.rounds);
-  props += (uint64_t)res.props; /* narrowings of an inconsistent node count too (propagate.c:78) */
-  if (res.status < 0) return PROP_ERROR;
-  for (size_t i = 0; i < g_size; i++)
-    if (g_out[i].lo != g_state[i].lo || g_out[i].hi != g_state[i].hi) {
-      struct val_t v = { g_out[i].lo, g_out[i].hi };
-      bind(&g_env[i], v, NULL);
-    }
-  return res.props;
+  return deliver(var, &res, g_out);
 }
 
 /* ---- trees whose terminals are the variables (root phase, single operators) ------------------ */
@@ -333,7 +498,8 @@ prop_result_t propagate_clauses(const struct clause_list_t *clauses) {
 /* sweeps to the fixpoint of `constr` pushed with `want`; writes the narrowed terminals back
  * (bind() when the terminal has an environment, plain store otherwise: propagate.c:75-83) */
 static prop_result_t propagate_tree(struct constr_t *constr, struct val_t want, const struct wand_expr_t *clause,
-                                    int recurse) {
+                                    int recurse, int64_t limit) {
+  eval_cache_drop();
   flat f;
   flat_slots(&f, constr);
   csgpu_model *gm = NULL;
@@ -347,7 +513,7 @@ static prop_result_t propagate_tree(struct constr_t *constr, struct val_t want, 
   }
   int32_t status = 0;
   TRACE("[dropin] tree propagate, %d clauses\n", hm->n_clauses);
-  if (csgpu_model_root_propagate(gm, &status) != CSGPU_OK) fatal_gpu("propagate");
+  if (csgpu_model_root_propagate_limit(gm, limit, &status, NULL) != CSGPU_OK) fatal_gpu("propagate");
   TRACE("[dropin]   -> %d\n", status);
   prop_result_t total = status;
   struct env_t **changed = NULL;
@@ -383,14 +549,94 @@ static prop_result_t propagate_tree(struct constr_t *constr, struct val_t want, 
 }
 
 prop_result_t propagate(struct constr_t *constr, size_t limit) {
-  (void)limit; /* the device runs to the fixpoint */
   g_root = constr;
   g_calls[1]++;
   struct val_t t = { 1, 1 };
-  return propagate_tree(constr, t, NULL, 0);
+  return propagate_tree(constr, t, NULL, 0, limit > (size_t)0x7ffffff0 ? -1 : (int64_t)limit);
 }
 
 /* ---- eval ----------------------------------------------------------------------------------------- */
+
+/* post-order list of the non-terminal nodes below c that are not valued yet */
+static void collect_nodes(const struct constr_t *c, pmap *seen, const struct constr_t ***list, size_t *n, size_t *cap) {
+  if (c->type->op == ' ' || pmap_get(seen, c) >= 0 || pmap_get(&g_eval_cache, c) >= 0) return;
+  pmap_put(seen, c, 1);
+  if (c->type->op == 'A') {
+    for (size_t i = 0; i < c->constr.wand.length; i++) collect_nodes(c->constr.wand.elems[i].constr, seen, list, n, cap);
+  } else {
+    collect_nodes(c->constr.expr.l, seen, list, n, cap);
+    if (c->constr.expr.r != NULL) collect_nodes(c->constr.expr.r, seen, list, n, cap);
+  }
+  if (*n == *cap) {
+    *cap = *cap ? *cap * 2 : 1024;
+    *list = (const struct constr_t **)realloc(*list, *cap * sizeof **list);
+  }
+  (*list)[(*n)++] = c;
+}
+
+static void eval_subtree_into_cache(const struct constr_t *top) {
+  pmap seen;
+  pmap_init(&seen, 1 << 12);
+  const struct constr_t **list = NULL;
+  size_t n = 0, cap = 0;
+  collect_nodes(top, &seen, &list, &n, &cap);
+  pmap_free(&seen);
+  if (n == 0) { free(list); return; }
+  /* a temporary model whose root wide-and has one element per collected node (wide-ands are valued from their
+   * elements afterwards: eval_wand, eval.c:233-255) */
+  flat f;
+  memset(&f, 0, sizeof f);
+  f.m = cs_model_new();
+  f.slot_mode = 1;
+  pmap_init(&f.nodes, 2 * n + 1024);
+  int32_t *kids = (int32_t *)malloc(n * sizeof *kids);
+  size_t n_kids = 0;
+  int32_t *kid_of = (int32_t *)malloc(n * sizeof *kid_of);
+  for (size_t i = 0; i < n; i++) {
+    kid_of[i] = -1;
+    if (list[i]->type->op == 'A') continue;
+    kid_of[i] = (int32_t)n_kids;
+    kids[n_kids++] = flat_node(&f, (struct constr_t *)list[i], 0);
+  }
+  csgpu_val *vals = (csgpu_val *)malloc((n_kids ? n_kids : 1) * sizeof *vals);
+  if (n_kids > 0) {
+    f.m->root = cs_model_add_wand(f.m, kids, (int32_t)n_kids);
+    csgpu_model *gm = NULL;
+    if (csgpu_model_from_host(f.m, 0, 0, &gm) != CSGPU_OK) fatal_gpu("eval");
+    if (csgpu_model_num_clauses(gm) != (int)n_kids) print_fatal("eval: %d clauses for %zu nodes", csgpu_model_num_clauses(gm), n_kids);
+    if (csgpu_model_eval_clauses_host(gm, vals) != CSGPU_OK) fatal_gpu("eval");
+    g_eval_launches++;
+    csgpu_model_free(gm);
+  } else {
+    cs_model_free(f.m);
+  }
+  flat_done(&f);
+  for (size_t i = 0; i < n; i++) { /* post-order: the elements of a wide-and are valued before it */
+    csgpu_val v;
+    if (kid_of[i] >= 0) {
+      v = vals[kid_of[i]];
+    } else {
+      int any_false = 0, all_true = 1;
+      for (size_t j = 0; j < list[i]->constr.wand.length; j++) {
+        const struct constr_t *e = list[i]->constr.wand.elems[j].constr;
+        cs_val ev;
+        if (e->type->op == ' ') ev = cs_interval(e->constr.term.val.lo, e->constr.term.val.hi);
+        else { const int32_t a = pmap_get(&g_eval_cache, e); ev = cs_interval(g_eval_vals[a].lo, g_eval_vals[a].hi); }
+        any_false |= cs_is_false(ev);
+        all_true &= cs_is_true(ev);
+      }
+      const cs_val r = cs_tv(all_true && !any_false, any_false);
+      v.lo = r.lo; v.hi = r.hi;
+    }
+    if (g_eval_n == g_eval_cap) {
+      g_eval_cap = g_eval_cap ? g_eval_cap * 2 : 4096;
+      g_eval_vals = (csgpu_val *)realloc(g_eval_vals, g_eval_cap * sizeof *g_eval_vals);
+    }
+    g_eval_vals[g_eval_n] = v;
+    pmap_put(&g_eval_cache, list[i], (int32_t)g_eval_n++);
+  }
+  free(vals); free(kids); free(kid_of); free(list);
+}
 
 static struct val_t eval_tree(const struct constr_t *constr) {
   struct val_t out = { 0, 1 };
@@ -403,7 +649,6 @@ static struct val_t eval_tree(const struct constr_t *constr) {
     }
     if (csgpu_model_set_domains(g_model, g_state) != CSGPU_OK) fatal_gpu("eval");
   }
-  flat f;
   if (g_model != NULL && constr == g_root) {
     int n = csgpu_model_num_clauses(g_model);
     csgpu_val *vals = (csgpu_val *)malloc((size_t)(n > 0 ? n : 1) * sizeof *vals);
@@ -420,29 +665,22 @@ static struct val_t eval_tree(const struct constr_t *constr) {
     out.hi = r.hi;
     return out;
   }
-  flat_slots(&f, (struct constr_t *)constr);
-  csgpu_model *gm = NULL;
-  if (csgpu_model_from_host(f.m, 0, 0, &gm) != CSGPU_OK) fatal_gpu("eval");
-  int n = csgpu_model_num_clauses(gm);
-  csgpu_val *vals = (csgpu_val *)malloc((size_t)(n > 0 ? n : 1) * sizeof *vals);
-  if (n < 0 || csgpu_model_eval_clauses_host(gm, vals) != CSGPU_OK) fatal_gpu("eval");
-  if (constr->type->op == 'A') { /* eval_wand over the clause values (eval.c:233-255) */
-    int any_false = 0, all_true = 1;
-    for (int c = 0; c < n; c++) {
-      cs_val v = cs_interval(vals[c].lo, vals[c].hi);
-      any_false |= cs_is_false(v);
-      all_true &= cs_is_true(v);
+  /* every non-terminal node below `top` becomes a clause of a temporary model: one launch values them all */
+  if (g_eval_cache.key == NULL) pmap_init(&g_eval_cache, 1 << 12);
+  int32_t at = pmap_get(&g_eval_cache, constr);
+  for (int pass = 0; at < 0 && pass < 2; pass++) {
+    const struct constr_t *top = constr;
+    if (pass == 0) {
+      if (g_eval_root_done || g_root == NULL) continue;
+      top = g_root; /* first question of a normalisation pass: value the whole root tree */
+      g_eval_root_done = 1;
     }
-    cs_val r = cs_tv(all_true && !any_false, any_false);
-    out.lo = r.lo;
-    out.hi = r.hi;
-  } else {
-    out.lo = vals[0].lo;
-    out.hi = vals[0].hi;
+    eval_subtree_into_cache(top);
+    at = pmap_get(&g_eval_cache, constr);
   }
-  free(vals);
-  csgpu_model_free(gm);
-  flat_done(&f);
+  if (at < 0) print_fatal("eval: node was not valued");
+  out.lo = g_eval_vals[at].lo;
+  out.hi = g_eval_vals[at].hi;
   return out;
 }
 
@@ -465,7 +703,7 @@ struct val_t eval_confl(const struct constr_t *constr) {
 #define PROP_VIA_GPU(NAME)                                                                         \
   prop_result_t propagate_##NAME(struct constr_t *constr, struct val_t val, const struct wand_expr_t *clause) { \
     g_calls[3]++;                                                                                  \
-    return propagate_tree(constr, val, clause, 1);                                                 \
+    return propagate_tree(constr, val, clause, 1, -1);                                             \
   }
 PROP_VIA_GPU(term) PROP_VIA_GPU(eq) PROP_VIA_GPU(lt) PROP_VIA_GPU(neg) PROP_VIA_GPU(add) PROP_VIA_GPU(mul)
 PROP_VIA_GPU(not) PROP_VIA_GPU(and) PROP_VIA_GPU(or)
@@ -474,7 +712,7 @@ PROP_VIA_GPU(not) PROP_VIA_GPU(and) PROP_VIA_GPU(or)
 prop_result_t propagate_wand(struct constr_t *constr, struct val_t val, const struct wand_expr_t *clause) {
   if (!(val.lo > 0 || val.hi < 0)) return 0;
   g_calls[3]++;
-  return propagate_tree(constr, val, clause, 1);
+  return propagate_tree(constr, val, clause, 1, -1);
 }
 
 prop_result_t propagate_confl(struct constr_t *constr, struct val_t val, const struct wand_expr_t *clause) {

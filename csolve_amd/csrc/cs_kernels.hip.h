@@ -95,6 +95,9 @@ struct cs_ctx {
   unsigned *mark;     /* LDS, next-round changed mask (events) or one flag word (sweeps) */
   int mark_is_flag;
   int fail, props, revisions;
+  int fail_var; /* a variable whose domain this lane saw become empty (-1: none / not attributable to one variable):
+                 * the reference bumps that variable's priority (propagate_term_confl, propagate.c:33-41) */
+  __device__ __forceinline__ void failed_at(int v) { fail = 1; fail_var = v; }
 
   __device__ __forceinline__ void touched(int v) {
     if (mark_is_flag) mark[0] = 1u;
@@ -105,7 +108,7 @@ struct cs_ctx {
     if (old < lo) {
       props++;
       touched(v);
-      if (lo > dom[v].hi) fail = 1;
+      if (lo > dom[v].hi) failed_at(v);
     }
   }
   __device__ __forceinline__ void lower_hi(int v, int hi) {
@@ -113,13 +116,13 @@ struct cs_ctx {
     if (old > hi) {
       props++;
       touched(v);
-      if (hi < dom[v].lo) fail = 1;
+      if (hi < dom[v].lo) failed_at(v);
     }
   }
   /* propagate_term (propagate.c:57-87): intersect dom[v] with want */
   __device__ __forceinline__ void narrow(int v, cs_val want) {
     cs_val d = dom[v];
-    if (d.lo > want.hi || d.hi < want.lo) { fail = 1; return; }
+    if (d.lo > want.hi || d.hi < want.lo) { failed_at(v); return; }
     int before = props;
     if (want.lo > d.lo) raise_lo(v, want.lo);
     if (want.hi < d.hi) lower_hi(v, want.hi);
@@ -127,6 +130,19 @@ struct cs_ctx {
     if (props == before + 2) props = before + 1;
   }
 };
+
+/* the variable a failed node reports in csgpu_result.rounds: the first lane that attributed its failure to a
+ * variable, else a variable whose bounds have crossed in `dom`, else -1 */
+__device__ __forceinline__ int cs_wave_fail_var(const cs_ctx &cx, const cs_val *dom, int n, int lane) {
+  const unsigned long long m = __ballot(cx.fail && cx.fail_var >= 0);
+  if (m != 0ull) return __builtin_amdgcn_readlane(cx.fail_var, __builtin_ctzll(m));
+  for (int v0 = 0; v0 < n; v0 += CS_WAVE) {
+    const int v = v0 + lane;
+    const unsigned long long c = __ballot(v < n && dom[v < n ? v : 0].lo > dom[v < n ? v : 0].hi);
+    if (c != 0ull) return v0 + __builtin_ctzll(c);
+  }
+  return -1;
+}
 
 /* X_u != X_w + d seen from u (both directions of the clause, propagate.c:123-136) */
 /* X_a < X_b + d pushed down to the two variables (propagate_lt true + propagate_add, propagate.c:139-200,
@@ -136,7 +152,7 @@ struct cs_ctx {
 __device__ __forceinline__ void cs_lt_enforce(cs_ctx &cx, int a, int b, int d) {
   const cs_val da = cx.dom[a], db = cx.dom[b];
   const long long ha = (long long)db.hi + d - 1, lb = (long long)da.lo - d + 1;
-  if (ha < da.lo || lb > db.hi) { cx.fail = 1; return; }
+  if (ha < da.lo || lb > db.hi) { cx.failed_at(ha < da.lo ? a : b); return; }
   if (ha < da.hi) cx.lower_hi(a, (int)ha);
   if (lb > db.lo) cx.raise_lo(b, (int)lb);
 }
@@ -180,7 +196,7 @@ __device__ __forceinline__ void cs_or2_revise(cs_ctx &cx, const int4 *lit) {
   const int4 l0 = lit[0], l1 = lit[1];
   const bool f0 = (long long)cx.dom[l0.x].lo >= (long long)cx.dom[l0.y].hi + l0.z; /* X_a >= X_b + d for sure */
   const bool f1 = (long long)cx.dom[l1.x].lo >= (long long)cx.dom[l1.y].hi + l1.z;
-  if (f0 && f1) cx.fail = 1;
+  if (f0 && f1) cx.failed_at(l1.x);
   else if (f0) cs_lt_enforce(cx, l1.x, l1.y, l1.z);
   else if (f1) cs_lt_enforce(cx, l0.x, l0.y, l0.z);
 }
@@ -430,6 +446,7 @@ __global__ __launch_bounds__(CS_BLOCK) void cs_propagate_events(cs_tables T, con
     cx.dom = dom;
     cx.mark_is_flag = 0;
     cx.fail = 0;
+    cx.fail_var = -1;
     cx.props = 0;
     cx.revisions = 0;
     if (nin.var >= 0) {
@@ -476,7 +493,7 @@ __global__ __launch_bounds__(CS_BLOCK) void cs_propagate_events(cs_tables T, con
           bits &= bits - 1u;
           /* a variable whose bounds crossed through racing lo/hi updates */
           const cs_val du = dom[u];
-          if (du.lo > du.hi) cx.fail = 1;
+          if (du.lo > du.hi) cx.failed_at(u);
           const int beg = TAB_LDS ? s_adj_off[u] : T.adj_off[u], end = TAB_LDS ? s_adj_off[u + 1] : T.adj_off[u + 1];
           for (int i = beg + lane; i < end && !cx.fail; i += CS_WAVE) {
             const int2 e = TAB_LDS ? s_adj[i] : T.adj[i];
@@ -516,6 +533,8 @@ __global__ __launch_bounds__(CS_BLOCK) void cs_propagate_events(cs_tables T, con
         dst[v] = d;
         open_vars += __popcll(__ballot(d.lo != d.hi));
       }
+    } else {
+      rounds = cs_wave_fail_var(cx, dom, n, lane); /* an inconsistent node reports the failing variable here */
     }
     if (lane == 0) {
       cs_node_out r;
@@ -591,6 +610,7 @@ __global__ __launch_bounds__(CS_BLOCK) void cs_propagate_clause_rounds(cs_tables
     cx.mark = flag;
     cx.mark_is_flag = 1;
     cx.fail = 0;
+    cx.fail_var = -1;
     cx.props = 0;
     cx.revisions = 0;
     int rounds = 0, failed = 0;
@@ -598,7 +618,7 @@ __global__ __launch_bounds__(CS_BLOCK) void cs_propagate_clause_rounds(cs_tables
       if (lane == 0) flag[0] = 0u;
       /* an interval emptied by the assignment, the incumbent or racing updates of lo and hi */
       for (int v = lane; v < n; v += CS_WAVE)
-        if (dom[v].lo > dom[v].hi) cx.fail = 1;
+        if (dom[v].lo > dom[v].hi) cx.failed_at(v);
       cs_wave_sync();
 #pragma unroll
       for (int q = 0; q < CPL; q++) {
@@ -636,6 +656,8 @@ __global__ __launch_bounds__(CS_BLOCK) void cs_propagate_clause_rounds(cs_tables
         dst[v] = d;
         open_vars += __popcll(__ballot(d.lo != d.hi));
       }
+    } else {
+      rounds = cs_wave_fail_var(cx, dom, n, lane); /* an inconsistent node reports the failing variable here */
     }
     if (lane == 0) {
       cs_node_out r;
@@ -1737,6 +1759,7 @@ __global__ __launch_bounds__(CS_BLOCK) void cs_propagate_sweeps(cs_tables T, con
   cx.mark = flags;
   cx.mark_is_flag = 1;
   cx.fail = 0;
+  cx.fail_var = -1;
   cx.props = 0;
   cx.revisions = 0;
   int rounds = 0;

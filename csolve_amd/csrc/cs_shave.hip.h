@@ -260,8 +260,21 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_shave(
           dh[r2] |= mh[r2];
         }
       };
-      /* the fixpoint; returns 1 as soon as a domain is empty (no flag to carry through the loops) */
+      /* the fixpoint; returns -1, or a variable whose domain has become empty (what the reference's
+       * propagate_term_confl would be called for, propagate.c:33-41) */
+      /* the valued variables after a push phase; -1, or a variable whose bounds have crossed */
+      auto settle = [&]() -> int {
+        int bad = -1;
+#pragma unroll
+        for (int r = R - 1; r >= 0; r--) {
+          const u64 c = __ballot(rlo[r] > rhi[r]);
+          if (c != 0ull) bad = __builtin_ctzll(c) + r * CS_WAVE;
+          val[r] = __ballot(rlo[r] == rhi[r]) & livemask[r];
+        }
+        return bad;
+      };
       auto fixpoint = [&]() -> int {
+        int fail_v = -1;
         for (;;) {
           /* (1) PUSH: every newly valued variable moves the bounds it sits on.  A valued variable's bounds do
            * not change any more, so "value - dmin" of every pusher of this round is taken from one register. */
@@ -278,13 +291,8 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_shave(
               push_var(r, ul, __builtin_amdgcn_readlane(cdv[r], ul));
             }
           }
-          u64 crossed = 0ull;
-#pragma unroll
-          for (int r = 0; r < R; r++) {
-            crossed |= __ballot(rlo[r] > rhi[r]);
-            val[r] = __ballot(rlo[r] == rhi[r]) & livemask[r];
-          }
-          if (crossed != 0ull) return 1;
+          fail_v = settle();
+          if (fail_v >= 0) return fail_v;
           /* (2a) Many moved bounds, few valued variables (an assignment on a bound of the root domains moves a bound
            * of every other queen): cheaper than verifying each moved bound against all valued variables is to let
            * every valued variable push again -- each sweep moves the bounds that are still forbidden by one more
@@ -306,13 +314,8 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_shave(
                 push_var(r, ul, __builtin_amdgcn_readlane(cdv[r], ul));
               }
             }
-            crossed = 0ull;
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-              crossed |= __ballot(rlo[r] > rhi[r]);
-              val[r] = __ballot(rlo[r] == rhi[r]) & livemask[r];
-            }
-            if (crossed != 0ull) return 1;
+            fail_v = settle();
+            if (fail_v >= 0) return fail_v;
           }
           /* (2) VERIFY: a moved bound stops at the first value no valued variable forbids.  Lane u holds the
            * table entry e of (w, k, u); its own value forbids the value rlo[u] + e - kb[w] of w, i.e. the
@@ -367,7 +370,7 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_shave(
                   cand += side == 0 ? step : -step;
                   if (lane == wl) { if (side == 0) rlo[r] = cand; else rhi[r] = cand; }
                   /* a bound that passed the other one is the failure: noticed after the loops (no exit from in here) */
-                  crossed |= (side == 0 ? cand > other : cand < other) ? 1ull : 0ull;
+                  if (side == 0 ? cand > other : cand < other) fail_v = wl + r * CS_WAVE;
                   if (cand == other) val[r] |= 1ull << wl; /* counts for the verifications that follow */
                 } else {
                   /* run-time slot count: the row is re-read per candidate */
@@ -387,14 +390,14 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_shave(
                   if (step != 0) {
                     cand += side == 0 ? step : -step;
                     if (lane == wl) { if (side == 0) rlo[r] = cand; else rhi[r] = cand; }
-                    crossed |= (side == 0 ? cand > other : cand < other) ? 1ull : 0ull;
+                    if (side == 0 ? cand > other : cand < other) fail_v = wl + r * CS_WAVE;
                     if (cand == other) val[r] |= 1ull << wl;
                   }
                 }
               }
             }
           }
-          if (crossed != 0ull) return 1;
+          if (fail_v >= 0) return fail_v;
           /* (3) variables that became values (and are supported) push next */
           u64 any_push = 0ull;
 #pragma unroll
@@ -402,14 +405,15 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_shave(
             push[r] = val[r] & ~pushed[r];
             any_push |= push[r];
           }
-          if (any_push == 0ull) return 0;
+          if (any_push == 0ull) return -1;
           /* a node that goes on cascading is a candidate for the tail of the launch (a few nodes cost 50 times the
            * average): from its second round on its wave is served first by the SIMD's arbiter */
           if (rounds == 0) __builtin_amdgcn_s_setprio(3);
           rounds++;
         }
       };
-      const int failed = fixpoint();
+      const int fail_var = fixpoint();
+      const int failed = fail_var >= 0;
       if (rounds != 0) __builtin_amdgcn_s_setprio(0);
 
       int open_vars = 0, shaved = 0;
@@ -432,7 +436,7 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_shave(
         my_result.status = failed ? -1 : open_vars;
         my_result.props = props;
         my_result.revisions = revisions;
-        my_result.rounds = rounds;
+        my_result.rounds = failed ? fail_var : rounds; /* an inconsistent node reports the failing variable here */
       }
     }
     if (lane < cnt) results[base + lane] = my_result;

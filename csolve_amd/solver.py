@@ -254,6 +254,24 @@ class Model:
         return res.status, res.props, out
 
 
+    def propagate_values(self, state: np.ndarray, var: int, values):
+        """Several values of `var` on one parent state, host buffers (the drop-in's sibling batch).
+        -> (results [count, 4], states_out [count, n_vars, 2]); rows of inconsistent nodes are unspecified"""
+        state = np.ascontiguousarray(state, dtype=np.int32)
+        values = np.ascontiguousarray(values, dtype=np.int32)
+        outs = np.empty((len(values),) + state.shape, dtype=np.int32)
+        res = np.empty((len(values), 4), dtype=np.int32)
+        check(load_library().csgpu_propagate_values(self._h, state.ctypes.data, var, values.ctypes.data, len(values),
+                                                    outs.ctypes.data, res.ctypes.data))
+        return res, outs
+
+    def root_propagate_limit(self, limit: int):
+        """propagate(root, limit): at most limit + 1 sweeps.  -> (status, rounds)"""
+        st, rounds = C.c_int32(), C.c_int32()
+        check(load_library().csgpu_model_root_propagate_limit(self._h, limit, C.byref(st), C.byref(rounds)))
+        return st.value, rounds.value
+
+
 def set_linear_fast_paths(on: bool):
     """Process-wide: whether models finalized from now on revise EQ / LT / two-literal OR clauses by direct
     bound propagation (default) or through the expression-tree interpreter (csgpu_set_linear_fast_paths)."""

@@ -113,6 +113,10 @@ int csolve_dropin_attach(struct env_t *env, size_t size, struct constr_t *root);
 void csolve_dropin_detach(void);
 /* device calls made so far: [0] propagate_clauses, [1] propagate, [2] eval, [3] single-op propagate */
 void csolve_dropin_counters(uint64_t out[4]);
+/* sibling batching of propagate_clauses: [0] batches launched, [1] calls served from a batch already there */
+void csolve_dropin_sibling_counters(uint64_t out[2]);
+/* seconds spent so far in [0] attach, [1] the device calls of propagate_clauses, [2] the rest of propagate_clauses */
+void csolve_dropin_seconds(double out[3]);
 
 #ifdef __cplusplus
 }

@@ -61,7 +61,10 @@ typedef struct csgpu_node {
 /* per-node result.  status: -1 = PROP_ERROR (csolve.h:84); otherwise the node is consistent and
  * status = number of variables that are still open (not a single value), 0 = complete assignment.
  * props = narrowing events (the reference's PROPS counter, propagate.c:77-78),
- * revisions = clause revisions performed, rounds = worklist rounds. */
+ * revisions = clause revisions performed, rounds = worklist rounds -- and for an INCONSISTENT node (status -1)
+ * the index of a variable whose domain became empty, or -1 if the kernel does not attribute the failure (kernels
+ * 1, 6, 7 do; the reference bumps that variable's priority, propagate_term_confl, propagate.c:33-41; which of
+ * several emptied variables is reported depends on the revision order). */
 typedef struct csgpu_result {
   int32_t status, props, revisions, rounds;
 } csgpu_result;
@@ -98,6 +101,12 @@ int csgpu_model_device_info(const csgpu_model *m, int64_t info[8]);
  * Gauss-Seidel sweeps, propagate.c:483; the device runs Jacobi rounds to the fixpoint,
  * which is the same state whenever the reference reaches its fixpoint within the limit.) */
 int csgpu_model_root_propagate(csgpu_model *m, int32_t *status);
+/* The same with the reference's `limit` (propagate.c:479-483: at most limit + 1 sweeps; limit < 0: none).  The
+ * device's sweeps revise all clauses of a round in parallel, the reference's one after the other (Gauss-Seidel),
+ * so k device rounds never narrow more than k reference sweeps: whenever the device reaches its fixpoint within
+ * limit + 1 rounds (*rounds, if wanted, says how many it took) the reference does too and the states are equal;
+ * when the limit cuts the device short the result is a sound but possibly wider state than the reference's. */
+int csgpu_model_root_propagate_limit(csgpu_model *m, int64_t limit, int32_t *status, int32_t *rounds);
 
 /* The root normalisation pass between the two root propagations (normalize(), reference
  * src/normalize.c:305-316, parser.y:66): a host-side rewrite of the trees (constant folding,
@@ -274,6 +283,13 @@ int64_t csgpu_search_solutions(const csgpu_search *s, int32_t *values, int64_t m
 /* MIN/MAX: the values ([n_vars], host memory) of a solution that attains the incumbent
  * (csgpu_search_stats.best); returns 1 if there is one, 0 if no solution was found yet */
 int csgpu_search_best_solution(const csgpu_search *s, int32_t *values);
+
+/* `count` values of variable `var` on ONE parent state, host buffers: node i assigns values[i].  results and
+ * states_out ([count][n_vars]; rows of inconsistent nodes unspecified) are host memory.  What the reference
+ * driver asks for one value at a time (step_val, csolve.c:331-338 -> check_assignment, csolve.c:247-261), in one
+ * launch; the drop-in shim serves the driver's following calls from it.  Synchronous. */
+int csgpu_propagate_values(const csgpu_model *m, const csgpu_val *state, int32_t var, const int32_t *values,
+                           int32_t count, csgpu_val *states_out, csgpu_result *results);
 
 /* Convenience for single nodes with host buffers (used by the drop-in shim):
  * uploads `state` (n_vars), runs one node, downloads the result.  Synchronous. */

@@ -34,6 +34,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 const char *main_name(void) { return "csolve_ref"; }
 
@@ -475,6 +476,38 @@ static enum order_t parse_order(const char *s) {
   return ORDER_NONE;
 }
 
+#ifdef CS_DROPIN_BUILD
+/* The driver draws its restart seeds from rand() (csolve.c:284), unseeded.  In a process that has loaded the HIP
+ * runtime other threads draw from the same libc generator, so the driver's sequence would differ from run to
+ * run.  The driver objects of THIS build therefore bind to a private generator that reproduces glibc's default
+ * sequence (TYPE_3 additive feedback, srand(1)); it is hidden, the runtime keeps using libc's. */
+static int cs_rand_f;
+__attribute__((visibility("hidden"))) int rand(void) {
+  static int32_t r[34];
+  static int ready;
+  if (!ready) {
+    int32_t t[344];
+    t[0] = 1;
+    for (int i = 1; i < 31; i++) {
+      int64_t v = (16807LL * t[i - 1]) % 2147483647;
+      if (v < 0) v += 2147483647;
+      t[i] = (int32_t)v;
+    }
+    for (int i = 31; i < 34; i++) t[i] = t[i - 31];
+    for (int i = 34; i < 344; i++) t[i] = (int32_t)((uint32_t)t[i - 31] + (uint32_t)t[i - 3]);
+    for (int i = 0; i < 34; i++) r[i] = t[310 + i];
+    ready = 1;
+    cs_rand_f = 0;
+  }
+  /* r holds the last 34 outputs of the recurrence x[k] = x[k-31] + x[k-3] as a ring */
+  const int k = cs_rand_f;
+  const uint32_t v = (uint32_t)r[(k + 34 - 31) % 34] + (uint32_t)r[(k + 34 - 3) % 34];
+  r[k] = (int32_t)v;
+  cs_rand_f = (k + 1) % 34;
+  return (int)(v >> 1);
+}
+#endif
+
 int main(int argc, char **argv) {
   if (argc < 3) {
     fprintf(stderr, "usage: csolve_ref solve|model|walk <file> ...\n");
@@ -508,7 +541,10 @@ int main(int argc, char **argv) {
 
   size_t size;
   struct env_t *env;
+  struct timespec ts0, ts1, ts2;
+  clock_gettime(CLOCK_MONOTONIC, &ts0);
   struct constr_t *norm = root_phase(path, &size, &env);
+  clock_gettime(CLOCK_MONOTONIC, &ts1);
 
   if (strcmp(cmd, "model") == 0) {
     if (argc < 4 || norm == NULL) return 1;
@@ -521,6 +557,7 @@ int main(int argc, char **argv) {
 
   if (strcmp(cmd, "solve") == 0) {
     if (norm != NULL) solve(size, env, norm); /* second half of the Input action (parser.y:86) */
+    clock_gettime(CLOCK_MONOTONIC, &ts2);
     fflush(stdout);
 #ifdef CS_DROPIN_BUILD
     {
@@ -529,15 +566,26 @@ int main(int argc, char **argv) {
       extern void csolve_dropin_counters(uint64_t out[4]);
       uint64_t k[4];
       csolve_dropin_counters(k);
-      printf("@DROPIN {\"propagate_clauses\": %lu, \"propagate\": %lu, \"eval\": %lu, \"single_op\": %lu}\n",
-             k[0], k[1], k[2], k[3]);
+      extern void csolve_dropin_sibling_counters(uint64_t out[2]);
+      uint64_t sb[2];
+      csolve_dropin_sibling_counters(sb);
+      extern void csolve_dropin_seconds(double out[3]);
+      double sec[3];
+      csolve_dropin_seconds(sec);
+      printf("@DROPIN {\"propagate_clauses\": %lu, \"propagate\": %lu, \"eval\": %lu, \"single_op\": %lu, "
+             "\"sibling_batches\": %lu, \"served_from_batch\": %lu, \"attach_seconds\": %.6f, "
+             "\"device_call_seconds\": %.6f, \"shim_host_seconds\": %.6f}\n", k[0], k[1], k[2], k[3], sb[0], sb[1],
+             sec[0], sec[1], sec[2]);
     }
 #endif
     printf("@STATS {\"feasible_root\": %s, \"calls\": %lu, \"cuts\": %lu, \"props\": %lu, \"confl\": %lu, "
-           "\"restarts\": %lu, \"solutions\": %lu, \"best\": %d, \"timeout\": %s}\n",
+           "\"restarts\": %lu, \"solutions\": %lu, \"best\": %d, \"timeout\": %s, \"root_seconds\": %.6f, "
+           "\"solve_seconds\": %.6f}\n",
            norm != NULL ? "true" : "false", stat_get_calls(), stat_get_cuts(), stat_get_props(),
            stat_get_confl(), stat_get_restarts(), shared()->solutions, objective_best(),
-           shared()->timeout ? "true" : "false");
+           shared()->timeout ? "true" : "false",
+           (double)(ts1.tv_sec - ts0.tv_sec) + 1e-9 * (double)(ts1.tv_nsec - ts0.tv_nsec),
+           (double)(ts2.tv_sec - ts1.tv_sec) + 1e-9 * (double)(ts2.tv_nsec - ts1.tv_nsec));
     return 0;
   }
   fprintf(stderr, "csolve_ref: unknown command %s\n", cmd);

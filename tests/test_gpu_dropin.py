@@ -39,3 +39,59 @@ def test_reference_driver_on_gpu_propagator(name, flags):
     if sols and "last_solution" in want:
         last = {k.strip(): int(v) for k, v in (kv.split(" = ") for kv in sols[-1][0].rstrip(", ").split(", "))}
         assert last == want["last_solution"]
+
+
+def _run(path, flags, env=None):
+    p = subprocess.run([BIN, "solve", path] + flags, capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, **(env or {})))
+    assert p.returncode == 0, p.stderr
+    stats = json.loads(re.search(r"@STATS (\{.*\})", p.stdout).group(1))
+    used = json.loads(re.search(r"@DROPIN (\{.*\})", p.stdout).group(1))
+    sols = re.findall(r"SOLUTION: (.*?)BEST: (-?\d+)", p.stdout)
+    last = None
+    if sols:
+        last = {k.strip(): int(v) for k, v in (kv.split(" = ") for kv in sols[-1][0].rstrip(", ").split(", "))}
+    return stats, used, last
+
+
+def _queens_valid(sol, n):
+    x = [sol[f"X{i}"] for i in range(1, n + 1)]
+    return (sorted(x) == list(range(1, n + 1)) and len({x[i] + i for i in range(n)}) == n and
+            len({x[i] - i for i in range(n)}) == n)
+
+
+@pytest.mark.skipif(not os.path.exists(BIN), reason="oracle/_ref/csolve_ref_dropin not built (needs the reference tree)")
+@pytest.mark.parametrize("n", [64, 128])
+def test_reference_driver_with_default_flags_on_gpu_propagator(n, tmp_path):
+    """The reference's driver with its DEFAULT heuristics (-f true: prefer failing variables, -r 100: Luby
+    restarts; only conflict learning is off) on the GPU propagator: queens-64 / queens-128 -- the instances the
+    deterministic mode does not finish -- are solved, the solution is a valid placement, the driver's
+    value iteration can be served from sibling batches (CSOLVE_DROPIN_SIBLINGS=1) without changing the search (same
+    CALLS, CUTS, RESTARTS and solution as one node per call), and the run is reproducible.  The shim bumps the priority of the variable the device
+    reports as emptied (propagate_term_confl, propagate.c:33-41)."""
+    from csolve_amd import problems
+    path = tmp_path / f"queens{n}.txt"
+    path.write_text(problems.queens(n))
+    stats, used, sol = _run(str(path), ["-c", "false"], env={"CSOLVE_DROPIN_SIBLINGS": "1"})
+    assert stats["solutions"] == 1 and sol is not None and _queens_valid(sol, n)
+    assert used["sibling_batches"] > 0 and used["served_from_batch"] > 0
+    assert used["sibling_batches"] + used["served_from_batch"] <= used["propagate_clauses"]
+    assert stats["calls"] < 100000  # the reference needs 430 / 4,045 with its own failure chains
+    plain, used1, sol1 = _run(str(path), ["-c", "false"])  # the default: one node per call
+    assert used1["sibling_batches"] == 0
+    for k in ("calls", "cuts", "restarts", "solutions"):
+        assert plain[k] == stats[k], k
+    assert sol1 == sol
+    again, _, sol2 = _run(str(path), ["-c", "false"])  # and the run is reproducible
+    assert again["calls"] == plain["calls"] and sol2 == sol1
+
+
+@pytest.mark.skipif(not os.path.exists(BIN), reason="oracle/_ref/csolve_ref_dropin not built (needs the reference tree)")
+def test_sibling_batches_keep_the_deterministic_trace():
+    """queens-16, deterministic flags: the trace of the all-CPU reference with the value iteration served from batches"""
+    stats = json.load(open(golden("solve_stats.json")))
+    want = next(r for r in stats if r["problem"] == "queens16" and r["flags"] == DET)
+    got, used, _ = _run(golden("problems", "queens16.txt"), DET, env={"CSOLVE_DROPIN_SIBLINGS": "1"})
+    assert used["served_from_batch"] > 0
+    for k in ("calls", "cuts", "solutions"):
+        assert got[k] == want[k]

@@ -148,3 +148,42 @@ def test_sets_only_layout_limits_and_empty_batches():
     dead[0, 3, :] = -1  # every value of variable 3 marked
     un = model.unpack_sets(dead)
     assert un[0, 3].tolist() == [1, 0] and torch.equal(un[0, :3], root[0, :3])
+
+
+def test_root_limit_and_failing_variable_and_value_batches():
+    """propagate(root, limit): a chain whose bounds move by one per sweep stops after limit + 1 rounds, wider than
+    the fixpoint and containing it; an inconsistent node names a variable whose domain emptied; several values of
+    one variable in one launch give what the single-node entry gives for each."""
+    from csolve_amd import problems
+    from csolve_amd.solver import Model, solve_root
+    text = "ANY; a < b; b < c; c < a + 90; 0 <= a; a <= 100; 0 <= b; b <= 100; 0 <= c; c <= 100;"
+    free = Model.from_text(text)
+    st, rounds = free.root_propagate_limit(-1)
+    fix = free.domains()
+    cut = Model.from_text(text)
+    st2, r2 = cut.root_propagate_limit(1)
+    assert st >= 0 and st2 >= 0 and r2 <= 2 <= rounds
+    d = cut.domains()
+    assert (d[:, 0] <= fix[:, 0]).all() and (d[:, 1] >= fix[:, 1]).all() and (d != fix).any()
+
+    model = solve_root(problems.queens(8))
+    root = model.domains()
+    for k in (1, 7):
+        if not model.qualifies(k):
+            continue
+        model.set_kernel(k)
+        # X1 = 1, then X2 = 2 is on X1's diagonal: X2 is emptied
+        st1, _, after = model.propagate_one(root, 0, 1, 1)
+        assert st1 >= 0
+        nodes = torch.tensor([[1, 2, 2, 0]], dtype=torch.int32, device="cuda")
+        out, res = model.propagate(torch.from_numpy(after[None].copy()).cuda(), nodes)
+        torch.cuda.synchronize()
+        assert int(res[0, 0]) == -1 and 0 <= int(res[0, 3]) < 8, (k, res.tolist())
+    model.set_kernel(0)
+    vals = [8, 1, 7, 2, 5]
+    res, outs = model.propagate_values(root, 3, vals)
+    for i, v in enumerate(vals):
+        st_one, props_one, out_one = model.propagate_one(root, 3, v, v)
+        assert (res[i, 0] < 0) == (st_one < 0)
+        if st_one >= 0:
+            assert res[i, 0] == st_one and res[i, 1] == props_one and (outs[i] == out_one).all()

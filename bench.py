@@ -119,6 +119,28 @@ def make_instances(model, count, seed, walks=8192, with_sets=False, restore_kern
 REF_BIN = os.path.join(ROOT, "oracle", "_ref", "csolve_ref")
 
 
+def reference_replay(text, n, states_in_np, nodes_np, count=None):
+    """The compiled reference (oracle/_ref/csolve_ref bench) on the first `count` instances: bind + propagate_clauses
+    per instance on one host core.  -> (stats dict, status [count] (-1 or PROPS), after [count, n, 2])"""
+    import subprocess
+    import tempfile
+    count = nodes_np.shape[0] if count is None else count
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        prob = os.path.join(tmp, "problem.txt")
+        open(prob, "w").write(text)
+        rec = np.concatenate([nodes_np[:count, 0:2], states_in_np[nodes_np[:count, 3]].reshape(count, 2 * n)], 1).astype(np.int32)
+        fin, fout = os.path.join(tmp, "inst.in"), os.path.join(tmp, "res.out")
+        with open(fin, "wb") as f:
+            np.array([0x4E495343, n, count], dtype=np.int32).tofile(f)
+            rec.tofile(f)
+        p = subprocess.run([REF_BIN, "bench", prob, fin, fout, "-c", "false"], capture_output=True, text=True)
+        if p.returncode != 0:
+            raise RuntimeError("csolve_ref bench failed: " + p.stderr)
+        stats = json.loads(p.stdout.split("@BENCH ", 1)[1])
+        raw = np.fromfile(fout, dtype=np.int32)[3:].reshape(count, 1 + 2 * n)
+        return stats, raw[:, 0].astype(np.int64), raw[:, 1:].reshape(count, n, 2)
+
+
 def cpu_baseline(args, text, model, states_in, nodes, states_out, res_h):
     """The reference CPU propagator on one host core over a bounded sample of the SAME instances,
     used at the same time as the checker of the device results on that sample.

@@ -364,6 +364,55 @@ def test_large_batches_agree_across_kernels(kind, size, count):
             assert torch.equal(sets[3], sets[k]), k
 
 
+@pytest.mark.parametrize("kind,size,count", [("queens", 64, 1 << 16), ("queens", 128, 1 << 16), ("sudoku", 5, 1 << 15)])
+def test_full_batches_against_the_compiled_reference(kind, size, count):
+    """Every instance of a bench-sized batch (BASELINE configs[1], the north-star instance, configs[2]) through every
+    kernel the selector can pick for the model -- state-only entry, resident-sets entry, sets-only entry -- against
+    the COMPILED REFERENCE replaying the same instances (oracle/_ref/csolve_ref bench: the reference's own bind() +
+    propagate_clauses() on one host core): verdict, fixpoint and PROPS of every single node, not a sample and not
+    another kernel of this library."""
+    import bench
+    from csolve_amd import problems
+    from csolve_amd.solver import solve_root
+    if not os.path.exists(bench.REF_BIN):
+        pytest.skip("oracle/_ref/csolve_ref not built (needs the reference tree)")
+    text = _text(kind, size)
+    model = solve_root(text)
+    n, fw = model.n_vars, model.forbidden_words()
+    states_in, nodes, forb_in = bench.make_instances(model, count, seed=31, walks=4096, with_sets=True, restore_kernel=0)
+    si, nd = states_in.cpu().numpy(), nodes.cpu().numpy()
+    _, status, after = bench.reference_replay(text, n, si, nd)
+    fail = status < 0
+    assert 0 < int(fail.sum()) < count
+
+    def check(out, res, what):
+        out, res = out.cpu().numpy(), res.cpu().numpy()
+        assert ((res[:, 0] < 0) == fail).all(), what
+        assert (out[~fail] == after[~fail]).all(), what
+        assert (res[~fail, 1] == status[~fail]).all(), what  # PROPS: order-independent on != networks
+        assert (res[~fail, 0] == (after[~fail][:, :, 0] != after[~fail][:, :, 1]).sum(1)).all(), what
+
+    ran = []
+    for k in (0, 7, 5, 4, 3, 2, 1):
+        if k and not model.qualifies(k):
+            continue
+        model.set_kernel(k)
+        out, res = model.propagate(states_in, nodes)
+        torch.cuda.synchronize()
+        check(out, res, f"state-only entry, kernel {k or model.kernel()}")
+        ran.append(k or model.kernel())
+        if k in (0, 5, 4, 3) and fw > 0:
+            out, _, res = model.propagate_fb(states_in, nodes, forb_in=forb_in)
+            torch.cuda.synchronize()
+            check(out, res, f"resident sets, kernel {k}")
+    model.set_kernel(0)
+    if model.qualifies(4):
+        sets_out, res = model.propagate_sets(model.pack_sets(states_in), nodes)
+        torch.cuda.synchronize()
+        check(model.unpack_sets(sets_out), res, "sets-only entry")
+    assert (7 in ran) == (size != 5), ran  # queens-64 / -128 take the shaving kernel, sudoku-25 (625 variables) kernel 3
+
+
 @pytest.mark.parametrize("name", ["ref_schedule", "schedule6_s1", "ref_wcet"])
 def test_linear_fast_paths_equal_the_tree_interpreter(name):
     """EQ / LT / two-literal OR clauses on the direct bound-propagation paths against the same clauses

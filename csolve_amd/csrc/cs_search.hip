@@ -73,6 +73,14 @@ struct csgpu_search {
   int32_t *d_solutions;           /* [max_solutions][n] */
   int32_t *d_best_solution;       /* [n] a solution attaining the incumbent (MIN/MAX) */
   int have_best_solution;
+  int32_t best_solution_value;    /* the objective value d_best_solution attains (it may have been overtaken by an engine
+                                   * that shares the incumbent word: then this engine has no best row to show) */
+  /* a shared incumbent (csgpu_search_share_incumbent): the engine whose word this one uses, and how many engines
+   * use this one's.  A lender is kept alive (csgpu_search_free deferred) until its last borrower is gone. */
+  csgpu_search *lender;
+  int borrowers, free_pending;
+  int device; /* the device the engine was created on; made current in the calling thread by every entry point
+               * (a fresh host thread starts on device 0) */
   int64_t max_solutions;
   csgpu_search_stats st;
   /* restarts (ANY): the states put from outside are kept to restart from */
@@ -659,7 +667,7 @@ __device__ __forceinline__ void cs_accept_block(const cs_val *__restrict__ child
           /* atomic: engines that share the incumbent accept concurrently */
           const int old = objective == CS_OBJ_MIN ? atomicMin(best, val) : atomicMax(best, val);
           if (objective == CS_OBJ_MIN ? val < old : val > old) {
-            burst[B_IMPROVED] = 1ull;
+            burst[B_IMPROVED] = 0x100000000ull | (unsigned)val; /* flag | the value the stored row attains */
             s_pick = idx;
           }
         }
@@ -899,6 +907,16 @@ __global__ __launch_bounds__(SB) void cs_move_rows(unsigned long long *__restric
 
 extern "C" void csgpu_search_free(csgpu_search *s) {
   if (s == NULL) return;
+  if (s->borrowers > 0) { /* other engines' kernels and graphs still write the incumbent word in s->d_counters */
+    s->free_pending = 1;
+    return;
+  }
+  if (s->lender != NULL) {
+    csgpu_search *l = s->lender;
+    s->lender = NULL;
+    if (--l->borrowers == 0 && l->free_pending) csgpu_search_free(l);
+  }
+  (void)hipSetDevice(s->device);
   (void)hipFree(s->pool_forb); (void)hipFree(s->d_child_forb); (void)hipFree(s->d_rebuild_nodes);
   (void)hipFree(s->pool); (void)hipFree(s->d_choice); (void)hipFree(s->d_child_off); (void)hipFree(s->d_block_sum); (void)hipFree(s->d_block_skip);
   (void)hipFree(s->d_nodes); (void)hipFree(s->d_child_states); (void)hipFree(s->d_complete_states);
@@ -923,6 +941,7 @@ extern "C" int csgpu_search_create(const csgpu_model *m, int64_t pool_capacity, 
   csgpu_search *s = (csgpu_search *)calloc(1, sizeof *s);
   s->m = m;
   s->n = n;
+  if (hipGetDevice(&s->device) != hipSuccess) { free(s); return fail(CSGPU_E_HIP, "hipGetDevice"); }
   s->objective = csgpu_model_objective(m);
   s->obj_var = csgpu_model_objective_var(m);
   /* widest root interval bounds the branching factor (domains only shrink below the root) */
@@ -1025,6 +1044,7 @@ extern "C" int csgpu_search_create(const csgpu_model *m, int64_t pool_capacity, 
 
 extern "C" int csgpu_search_put(csgpu_search *s, const csgpu_val *d_states, int64_t count) {
   if (s == NULL || (count > 0 && d_states == NULL) || count < 0) return fail(CSGPU_E_ARG, "bad argument");
+  if (hipSetDevice(s->device) != hipSuccess) return fail(CSGPU_E_HIP, "hipSetDevice");
   if (s->top + count > s->cap) return fail(CSGPU_E_LIMIT, "state pool is full");
   if (count > 0)
     HIP_OK(hipMemcpy(s->pool + (size_t)s->top * s->n, d_states, (size_t)count * s->n * sizeof(cs_val),
@@ -1067,6 +1087,7 @@ extern "C" int csgpu_search_put(csgpu_search *s, const csgpu_val *d_states, int6
 
 extern "C" int csgpu_search_reset(csgpu_search *s) {
   if (s == NULL) return fail(CSGPU_E_ARG, "bad argument");
+  if (hipSetDevice(s->device) != hipSuccess) return fail(CSGPU_E_HIP, "hipSetDevice");
   s->top = 0;
   s->peak = 0;
   memset(&s->st, 0, sizeof s->st);
@@ -1084,6 +1105,7 @@ extern "C" int csgpu_search_reset(csgpu_search *s) {
 
 extern "C" int csgpu_search_put_host(csgpu_search *s, const csgpu_val *states, int64_t count) {
   if (s == NULL || (count > 0 && states == NULL) || count < 0) return fail(CSGPU_E_ARG, "bad argument");
+  if (hipSetDevice(s->device) != hipSuccess) return fail(CSGPU_E_HIP, "hipSetDevice");
   if (count == 0) return CSGPU_OK;
   cs_val *tmp = NULL;
   const size_t bytes = (size_t)count * s->n * sizeof(cs_val);
@@ -1102,6 +1124,7 @@ extern "C" int csgpu_search_set_restart(csgpu_search *s, int64_t iterations) {
 
 extern "C" int csgpu_search_take(csgpu_search *s, csgpu_val *d_states, int64_t max, int64_t *count) {
   if (s == NULL || d_states == NULL || count == NULL || max < 0) return fail(CSGPU_E_ARG, "bad argument");
+  if (hipSetDevice(s->device) != hipSuccess) return fail(CSGPU_E_HIP, "hipSetDevice");
   int64_t k = max < s->top ? max : s->top;
   *count = k;
   if (k == 0) return CSGPU_OK;
@@ -1123,13 +1146,17 @@ extern "C" int csgpu_search_take(csgpu_search *s, csgpu_val *d_states, int64_t m
 
 extern "C" int csgpu_search_set_parents(csgpu_search *s, int64_t parents_per_iteration) {
   if (s == NULL || parents_per_iteration < 1) return fail(CSGPU_E_ARG, "bad argument");
-  s->parents_limit = parents_per_iteration < s->max_parents ? parents_per_iteration : s->max_parents;
+  const int64_t limit = parents_per_iteration < s->max_parents ? parents_per_iteration : s->max_parents;
+  if ((s->lender != NULL || s->borrowers > 0) && (limit > SMALL_PARENTS || limit * s->max_width > s->max_children))
+    return fail(CSGPU_E_STATE, "engines that share an incumbent run device-driven iterations: at most 256 parents per iteration");
+  s->parents_limit = limit;
   s->parents_max = s->parents_limit; /* an explicit setting is taken literally */
   return CSGPU_OK;
 }
 
 extern "C" int csgpu_search_set_best(csgpu_search *s, int32_t best) {
   if (s == NULL) return fail(CSGPU_E_ARG, "bad argument");
+  if (hipSetDevice(s->device) != hipSuccess) return fail(CSGPU_E_HIP, "hipSetDevice");
   const int rcf = flush_accept_results(s); /* an unread incumbent of the last iteration must not be overwritten */
   if (rcf != CSGPU_OK) return rcf;
   int better = (s->objective == CS_OBJ_MIN && best < s->st.best) || (s->objective == CS_OBJ_MAX && best > s->st.best);
@@ -1143,6 +1170,7 @@ extern "C" int csgpu_search_set_best(csgpu_search *s, int32_t best) {
 extern "C" int csgpu_search_share_incumbent(csgpu_search *s, csgpu_search *with) {
   if (s == NULL || with == NULL || s->objective != with->objective || s->obj_var != with->obj_var)
     return fail(CSGPU_E_ARG, "bad argument");
+  if (hipSetDevice(s->device) != hipSuccess) return fail(CSGPU_E_HIP, "hipSetDevice");
   if (s->objective != CS_OBJ_MIN && s->objective != CS_OBJ_MAX) return CSGPU_OK; /* nothing to share */
   if (!burst_applicable(s) || !burst_applicable(with))
     return fail(CSGPU_E_STATE, "a shared incumbent needs the device-driven iterations");
@@ -1154,7 +1182,13 @@ extern "C" int csgpu_search_share_incumbent(csgpu_search *s, csgpu_search *with)
   HIP_OK(hipMemcpy(&theirs, with->d_best, sizeof(int), hipMemcpyDeviceToHost));
   const int best = s->objective == CS_OBJ_MIN ? (mine < theirs ? mine : theirs) : (mine > theirs ? mine : theirs);
   HIP_OK(hipMemcpy(with->d_best, &best, sizeof(int), hipMemcpyHostToDevice));
-  s->d_best = with->d_best;
+  if (s == with || s->lender == with) return CSGPU_OK;
+  if (s->borrowers > 0) return fail(CSGPU_E_STATE, "an engine whose incumbent word is shared by others cannot borrow one itself");
+  csgpu_search *owner = with->lender != NULL ? with->lender : with; /* chains collapse onto the engine that owns the word */
+  if (s->lender != NULL && --s->lender->borrowers == 0 && s->lender->free_pending) csgpu_search_free(s->lender);
+  s->lender = owner;
+  owner->borrowers++;
+  s->d_best = owner->d_best;
   s->st.best = best;
   if (s->burst_exec != NULL) { /* the graph holds the old pointer */
     (void)hipGraphExecDestroy(s->burst_exec);
@@ -1174,6 +1208,7 @@ static int apply_accept_results(csgpu_search *s, unsigned long long solutions_to
     hipLaunchKernelGGL(cs_pick_best, dim3(1), dim3(64), 0, 0, s->d_complete_states, s->d_truth, (int)s->pending_complete,
                        s->n, s->objective, s->obj_var, best, s->d_best_solution);
     s->have_best_solution = 1;
+    s->best_solution_value = best;
   }
   if (s->objective == CS_OBJ_MIN || s->objective == CS_OBJ_MAX) s->st.best = best;
   s->pending_complete = 0;
@@ -1485,12 +1520,16 @@ static int run_burst(csgpu_search *s, int64_t budget, int64_t *done) {
   s->st.revisions += h[B_REVS];
   s->st.solutions = h[B_COUNT + C_SOLUTIONS];
   if (s->objective == CS_OBJ_MIN || s->objective == CS_OBJ_MAX) s->st.best = *(const int *)(h + B_COUNT + C_COUNT);
-  if (h[B_IMPROVED] != 0ull) s->have_best_solution = 1;
+  if (h[B_IMPROVED] != 0ull) {
+    s->have_best_solution = 1;
+    s->best_solution_value = (int32_t)(uint32_t)h[B_IMPROVED];
+  }
   return CSGPU_OK;
 }
 
 extern "C" int csgpu_search_run(csgpu_search *s, int64_t max_iterations, csgpu_search_stats *stats) {
   if (s == NULL || stats == NULL) return fail(CSGPU_E_ARG, "bad argument");
+  if (hipSetDevice(s->device) != hipSuccess) return fail(CSGPU_E_HIP, "hipSetDevice");
   for (int64_t it = 0; it < max_iterations; it++) {
     if (s->top == 0) break;
     if (s->objective == CS_OBJ_ANY && s->st.solutions > 0) break;
@@ -1543,6 +1582,7 @@ extern "C" int csgpu_search_run(csgpu_search *s, int64_t max_iterations, csgpu_s
 
 extern "C" int64_t csgpu_search_solutions(const csgpu_search *s, int32_t *values, int64_t max) {
   if (s == NULL || values == NULL || max < 0) return CSGPU_E_ARG;
+  if (hipSetDevice(s->device) != hipSuccess) return fail(CSGPU_E_HIP, "hipSetDevice");
   unsigned long long stored = 0;
   if (hipMemcpy(&stored, s->d_counters + C_STORED, sizeof stored, hipMemcpyDeviceToHost) != hipSuccess) return CSGPU_E_HIP;
   int64_t k = (int64_t)stored;
@@ -1555,7 +1595,9 @@ extern "C" int64_t csgpu_search_solutions(const csgpu_search *s, int32_t *values
 
 extern "C" int csgpu_search_best_solution(const csgpu_search *s, int32_t *values) {
   if (s == NULL || values == NULL) return CSGPU_E_ARG;
-  if (!s->have_best_solution) return 0;
+  if (hipSetDevice(s->device) != hipSuccess) return fail(CSGPU_E_HIP, "hipSetDevice");
+  /* with a shared incumbent another engine may hold the row that attains it */
+  if (!s->have_best_solution || s->best_solution_value != s->st.best) return 0;
   if (hipMemcpy(values, s->d_best_solution, (size_t)s->n * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess)
     return CSGPU_E_HIP;
   return 1;

@@ -172,8 +172,14 @@ class LaneSearch:
     device idle between them (four ranks sharing one GPU finish a schedule.txt-style MIN search 1.8x sooner than one
     rank).  The lanes are what ranks are to ShardedSearch -- own pool, own stream (the engine's device-driven
     bursts), same exchange of incumbent, termination and open states after every slice -- without processes or
-    collectives: the engines' calls release the GIL and their bursts overlap on the device.  The exchange
-    decisions are functions of the lanes' statistics only, so a run is reproducible whatever the thread timing.
+    collectives: the engines' calls release the GIL and their bursts overlap on the device.
+
+    Reproducibility: ANY and ALL runs are reproducible whatever the thread timing (the exchange decisions are
+    functions of the lanes' statistics at slice boundaries only).  MIN / MAX runs share ONE incumbent word in device
+    memory that every lane's accept kernel updates while the others are in the middle of a slice, so which nodes a
+    lane cuts depends on when a neighbour's improvement lands: the optimum ("best") is the same in every run, the
+    node / cut / iteration counts are not.  The row attaining the optimum is held by the lane that found it
+    (best_solution()).
     """
 
     def __init__(self, engines, objective: int, slice_iterations: int = 32, seed_states_per_lane: int = 64,
@@ -234,3 +240,12 @@ class LaneSearch:
         totals["done"] = int(all(s["done"] for s in stats) or (self.objective == OBJ_ANY and totals["solutions"] > 0))
         totals["lanes"] = [s["nodes"] for s in stats]
         return totals
+
+    def best_solution(self):
+        """MIN / MAX: the values of a solution attaining the lanes' common incumbent (the lane that found it holds the
+        row; the others report none), or None"""
+        for e in self.engines:
+            row = e.best_solution() if hasattr(e, "best_solution") else None
+            if row is not None:
+                return row
+        return None

@@ -324,9 +324,11 @@ class Search:
         check(load_library().csgpu_search_set_restart(self._h, int(iterations)))
 
     def share_incumbent(self, other: "Search"):
-        """keep the incumbent in `other`'s word of device memory (MIN / MAX engines of one model on one device)"""
+        """keep the incumbent in `other`'s word of device memory (MIN / MAX engines of one model on one device).
+        While shared, set_parents beyond the device-driven limit is refused, best_solution() answers only on the
+        engine whose own row attains the incumbent, and the library keeps the lender's memory until the last
+        borrower is freed."""
         check(load_library().csgpu_search_share_incumbent(self._h, other._h))
-        self._shares = other  # keeps the owner of the word alive
 
     def set_best(self, best: int):
         check(load_library().csgpu_search_set_best(self._h, int(best)))

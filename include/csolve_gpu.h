@@ -268,8 +268,15 @@ int csgpu_search_set_restart(csgpu_search *s, int64_t iterations);
 int csgpu_search_set_best(csgpu_search *s, int32_t best);
 /* MIN / MAX engines of the same model on one device: from now on `s` keeps its incumbent in `with`'s word of
  * device memory (the analogue of the reference's shared page, csolve.c:86-97): what one engine accepts bounds
- * the very next fixpoints of the other.  `with` must outlive `s`; csgpu_search_reset of either resets the word.
- * Needs the device-driven iterations (CSGPU_E_STATE otherwise); a no-op for ANY / ALL. */
+ * the very next fixpoints of the other.  If `with` borrows itself, `s` borrows from the same owner; an engine
+ * that lends cannot borrow (CSGPU_E_STATE).  Lifetime: csgpu_search_free of a lender is deferred by the library
+ * until its last borrower has been freed (the handle must not be used after the call all the same).
+ * csgpu_search_reset of either resets the word.  Needs the device-driven iterations (CSGPU_E_STATE otherwise),
+ * and while shared csgpu_search_set_parents refuses a setting that would leave them (CSGPU_E_STATE).
+ * csgpu_search_best_solution answers 1 only on the engine whose stored row attains the current incumbent
+ * (after csgpu_search_run / csgpu_search_set_best have brought its statistics up to date); the others answer 0.
+ * With several engines accepting concurrently, node counts of a MIN / MAX run depend on timing; the optimum
+ * does not.  A no-op for ANY / ALL. */
 int csgpu_search_share_incumbent(csgpu_search *s, csgpu_search *with);
 /* run up to max_iterations iterations (stops early when done).  ANY/MIN/MAX iterations are enqueued
  * sixteen at a time as one hipGraph with the bookkeeping between them on the device (pool top, child

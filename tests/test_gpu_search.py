@@ -288,3 +288,50 @@ def test_lanes_on_one_gpu_reach_the_same_results():
         assert tot["done"] == 1 and tot["best"] == 31
         rows = [e.best_solution() for e in lanes]
         assert any(r is not None and r[model.objective_var] == 31 for r in rows)
+        # only a row that attains the common incumbent is ever shown; LaneSearch picks it
+        assert all(r is None or r[model.objective_var] == 31 for r in rows)
+
+
+def test_a_shared_incumbent_survives_its_owner_and_refuses_to_be_decoupled():
+    """csgpu_search_share_incumbent: the lender may be freed first (its memory stays until the last borrower is
+    gone), set_parents cannot take a sharing engine off the device-driven iterations, and an engine whose own
+    row was overtaken by another engine's improvement reports no best solution instead of a stale one."""
+    from csolve_amd import problems
+    from csolve_amd._lib import CsolveError
+    from csolve_amd.solver import Search, solve_root
+    model = solve_root(problems.schedule(8, 1))
+    lender = Search(model, 1 << 18, 1 << 14)
+    a = Search(model, 1 << 18, 1 << 20)  # room for more parents per iteration than the device-driven path takes
+    b = Search(model, 1 << 18, 1 << 14)
+    a.share_incumbent(lender)
+    b.share_incumbent(a)  # collapses onto the lender
+    with pytest.raises(CsolveError):
+        lender.share_incumbent(a)  # a lender cannot borrow
+    with pytest.raises(CsolveError):
+        a.set_parents(1 << 20)  # would switch `a` to host-driven iterations that bypass the shared word
+    a.set_parents(64)
+    lender.close()  # deferred inside the library
+    torch.cuda.synchronize()
+    # `a` finds an incumbent; `b`, which shares the word, is bounded by it
+    a.put(model.root_state())
+    st = a.run(40)
+    while st["best"] == 2**31 - 1 and not st["done"]:
+        st = a.run(8)
+    first = st["best"]
+    row = a.best_solution()
+    assert row is not None and row[model.objective_var] == first
+    b.put(model.root_state())
+    stb = b.run()
+    assert stb["done"] == 1 and stb["best"] == 31
+    rb = b.best_solution()
+    sta = a.run()
+    assert sta["done"] == 1 and sta["best"] == 31
+    ra = a.best_solution()
+    # whoever reached 31 first holds the row; the other one's row (if any) was overtaken and is not shown
+    rows = [r for r in (ra, rb) if r is not None]
+    assert len(rows) >= 1 and all(r[model.objective_var] == 31 for r in rows)
+    if first > 31:
+        assert rb is not None or ra is not None
+    a.close()
+    b.close()
+    torch.cuda.synchronize()

@@ -267,8 +267,8 @@ def search_workload(args, rank, world, local, dist):
     def once():
         eng.reset()
         sh = ShardedSearch(eng, model.objective, n, rank, world, dist, engine_device="cuda", comm_device=comm,
-                           slice_iterations=args.slice or (8 if model.objective == 1 else 32),  # 1 = ALL (csolve_amd/parallel.py)
-                           seed_states_per_rank=256, low_water=4096)
+                           slice_iterations=args.slice or (64 if model.objective == 1 else 256),  # 1 = ALL; a dry rank calls the exchange earlier
+                           seed_states_per_rank=256, low_water=4096, poll_iterations=args.poll)
         local_stats, totals = sh.run(model.root_state(), args.search_slices if args.search_slices > 0 else 1 << 40)
         return local_stats, totals, sh
 
@@ -288,12 +288,21 @@ def search_workload(args, rank, world, local, dist):
     el = torch.tensor([t1 - t0], dtype=torch.float64, device=comm)
     moved = torch.tensor([sh.states_moved], dtype=torch.int64, device=comm)
     share = torch.tensor([local_stats["nodes"]], dtype=torch.int64, device=comm)
+    # the last step's clocks of every rank: where a rank's time went (diagnosis of the scaling runs)
+    put_s, put_n = eng.put_cost()
+    clocks = torch.tensor([sh.idle_fraction(), sh.seconds["total"], sh.seconds["seed"], sh.seconds["busy"],
+                           sh.seconds["exchange"], put_s, float(put_n), float(sh.exchanges), float(sh.early_exchanges)],
+                          dtype=torch.float64, device=comm).unsqueeze(0)
     if dist is not None:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(moved, op=dist.ReduceOp.SUM)
         gathered = torch.empty(world, dtype=torch.int64, device=comm)
         dist.all_gather_into_tensor(gathered, share)
         share = gathered
+        allc = torch.empty((world, clocks.shape[1]), dtype=torch.float64, device=comm)
+        dist.all_gather_into_tensor(allc, clocks)
+        clocks = allc
+    clocks = clocks.cpu().tolist()
     elapsed = float(el.item())
     if rank == 0:
         print(json.dumps({
@@ -308,7 +317,15 @@ def search_workload(args, rank, world, local, dist):
                        "nodes": totals["nodes"], "cuts": totals["cuts"], "props": totals["props"],
                        "iterations": totals["iterations"], "states_moved_between_ranks": int(moved.item()),
                        "nodes_per_rank": share.cpu().tolist(), "comm": args.comm,
-                       "stopped_after_slices": args.search_slices or None}}))
+                       "process_group": None if dist is None else dist.get_backend(),
+                       "stopped_after_slices": args.search_slices or None},
+            # one entry per rank, last step: idle = share of the time after seeding not spent inside the engine;
+            # put = csgpu_search_put (copy + rebuilding the forbidden sets of seeded / stolen states)
+            "ranks": [{"idle_fraction": round(c[0], 4), "seconds": round(c[1], 6), "seed_seconds": round(c[2], 6),
+                       "busy_seconds": round(c[3], 6), "exchange_seconds": round(c[4], 6),
+                       "put_seconds": round(c[5], 6), "put_states": int(c[6]),
+                       "put_fraction": round(c[5] / c[1], 5) if c[1] > 0 else None,
+                       "transfers": int(c[7]), "early_exchanges": int(c[8])} for c in clocks]}))
 
 
 def main():
@@ -335,6 +352,10 @@ def main():
                          "with resident forbidden sets; sets = csgpu_propagate_batch_sets (bit-vector states)")
     ap.add_argument("--no-queens128", action="store_true", help="skip the queens-128 sub-record of the default run")
     ap.add_argument("--workload", choices=["propagate", "search"], default="propagate")
+    ap.add_argument("--process-group", action="store_true", help="create the process group even for one rank (the "
+                    "collectives of the search workload then run over RCCL / gloo with world size 1)")
+    ap.add_argument("--poll", type=int, default=4, help="search workload: iterations between two looks at the node's "
+                    "status page")
     ap.add_argument("--search-queens", type=int, default=17, help="queens-N tree of the search workload (ALL: 17 is "
                     "95,815,104 solutions, 6.2e9 nodes, about a second on one GPU)")
     ap.add_argument("--search-objective", choices=["ALL", "ANY"], default="ALL")
@@ -343,8 +364,8 @@ def main():
     ap.add_argument("--pool", type=int, default=0, help="search workload: rows of the state pool (default: 8 x --children)")
     ap.add_argument("--children", type=int, default=0, help="search workload: children per iteration at most "
                     "(default: 2^21 for models of at most 32 variables, else 2^19)")
-    ap.add_argument("--slice", type=int, default=0, help="search iterations between rank exchanges (default: 8 for ALL, "
-                    "whose iterations are large batches; 32 for ANY / MIN / MAX = two device-driven bursts)")
+    ap.add_argument("--slice", type=int, default=0, help="search iterations between regular rank exchanges (default: 64 for ALL, "
+                    "256 for ANY / MIN / MAX; a rank that runs dry calls the exchange earlier through the status page)")
     ap.add_argument("--search-slices", type=int, default=0,
                     help="stop a search after this many slices (0 = run to the end): ALL on trees too large to finish")
     ap.add_argument("--comm", choices=["nccl", "gloo"], default="nccl")
@@ -367,8 +388,12 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or args.process_group:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.comm == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:

@@ -103,6 +103,7 @@ def load_library():
     L.csgpu_search_put_host.argtypes = [vp, vp, i64]
     L.csgpu_search_take.argtypes = [vp, vp, i64, C.POINTER(i64)]
     L.csgpu_search_set_best.argtypes = [vp, i32]
+    L.csgpu_search_put_cost.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64)]
     L.csgpu_search_share_incumbent.argtypes = [vp, vp]
     L.csgpu_search_set_parents.argtypes = [vp, i64]
     L.csgpu_search_set_restart.argtypes = [vp, i64]

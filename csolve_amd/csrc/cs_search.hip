@@ -5,6 +5,7 @@
  * true (update_solution 222-244), keep the incumbent (objective.c:81-126).  The reference walks
  * this tree depth-first one node at a time; here whole frontiers are expanded per launch. */
 #include <hip/hip_runtime.h>
+#include <chrono>
 
 #include <stdint.h>
 #include <stdio.h>
@@ -79,6 +80,8 @@ struct csgpu_search {
    * use this one's.  A lender is kept alive (csgpu_search_free deferred) until its last borrower is gone. */
   csgpu_search *lender;
   int borrowers, free_pending;
+  double put_seconds;     /* host time spent in csgpu_search_put / put_host (copy + rebuilding the forbidden sets) */
+  int64_t put_states;
   int device; /* the device the engine was created on; made current in the calling thread by every entry point
                * (a fresh host thread starts on device 0) */
   int64_t max_solutions;
@@ -1042,9 +1045,29 @@ extern "C" int csgpu_search_create(const csgpu_model *m, int64_t pool_capacity, 
   return CSGPU_OK;
 }
 
+static int search_put(csgpu_search *s, const csgpu_val *d_states, int64_t count);
+
 extern "C" int csgpu_search_put(csgpu_search *s, const csgpu_val *d_states, int64_t count) {
   if (s == NULL || (count > 0 && d_states == NULL) || count < 0) return fail(CSGPU_E_ARG, "bad argument");
   if (hipSetDevice(s->device) != hipSuccess) return fail(CSGPU_E_HIP, "hipSetDevice");
+  const auto t0 = std::chrono::steady_clock::now();
+  int rc = search_put(s, d_states, count);
+  if (rc == CSGPU_OK && count > 0) {
+    HIP_OK(hipDeviceSynchronize()); /* the rebuild launches are part of the cost */
+    s->put_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    s->put_states += count;
+  }
+  return rc;
+}
+
+extern "C" int csgpu_search_put_cost(const csgpu_search *s, double *seconds, int64_t *states) {
+  if (s == NULL || seconds == NULL || states == NULL) return fail(CSGPU_E_ARG, "bad argument");
+  *seconds = s->put_seconds;
+  *states = s->put_states;
+  return CSGPU_OK;
+}
+
+static int search_put(csgpu_search *s, const csgpu_val *d_states, int64_t count) {
   if (s->top + count > s->cap) return fail(CSGPU_E_LIMIT, "state pool is full");
   if (count > 0)
     HIP_OK(hipMemcpy(s->pool + (size_t)s->top * s->n, d_states, (size_t)count * s->n * sizeof(cs_val),
@@ -1096,6 +1119,8 @@ extern "C" int csgpu_search_reset(csgpu_search *s) {
   s->since_restart = 0;
   s->luby_threshold = 1;
   s->luby_counter = 1;
+  s->put_seconds = 0.0;
+  s->put_states = 0;
   s->have_best_solution = 0;
   s->pending_complete = 0;
   HIP_OK(hipMemset(s->d_counters, 0, sizeof(unsigned long long) * C_COUNT));

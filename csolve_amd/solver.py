@@ -333,6 +333,12 @@ class Search:
     def set_best(self, best: int):
         check(load_library().csgpu_search_set_best(self._h, int(best)))
 
+    def put_cost(self):
+        """-> (seconds, states): host time put() has taken since reset() (copy + rebuilding the forbidden sets)"""
+        sec, cnt = C.c_double(), C.c_int64()
+        check(load_library().csgpu_search_put_cost(self._h, C.byref(sec), C.byref(cnt)))
+        return sec.value, cnt.value
+
     def run(self, max_iterations: int = 1 << 62) -> dict:
         st = SearchStats()
         check(load_library().csgpu_search_run(self._h, max_iterations, C.byref(st)))

@@ -264,6 +264,9 @@ int csgpu_search_set_parents(csgpu_search *s, int64_t parents_per_iteration);
  * 264-276, default 100); every restart tries the values in a different pseudo-random rotation.
  * Default 64; 0 disables restarts. */
 int csgpu_search_set_restart(csgpu_search *s, int64_t iterations);
+/* host time csgpu_search_put / put_host have taken since the last reset (device copy + rebuilding the forbidden
+ * sets of the arriving states, which travel between ranks without them) and the states they brought */
+int csgpu_search_put_cost(const csgpu_search *s, double *seconds, int64_t *states);
 /* merge an incumbent found elsewhere (objective_best of the shared page, objective.c:89-93) */
 int csgpu_search_set_best(csgpu_search *s, int32_t best);
 /* MIN / MAX engines of the same model on one device: from now on `s` keeps its incumbent in `with`'s word of

@@ -1,5 +1,5 @@
-"""CPU tests (gloo, world_size 2 and 3) of the multi-rank search coordinator: seeding from rank 0,
-work stealing of open states, incumbent exchange, termination.  The engines are the oracle-backed
+"""CPU tests (gloo, world_size 2, 3 and 5) of the multi-rank search coordinator: seeding by every rank,
+the shared status page, work stealing of open states, incumbent exchange, termination.  The engines are the oracle-backed
 CPU stand-in (tests/cpu_engine.py); the coordinator code is exactly what runs over RCCL."""
 import os
 import socket
@@ -32,7 +32,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, text, out_q):
+def _worker(rank, world, port, text, out_q, options=None):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
@@ -50,20 +50,21 @@ def _worker(rank, world, port, text, out_q):
     om.index()
     eng = OracleEngine(om)
     sh = ShardedSearch(eng, om.view.objective, om.n_vars, rank, world, dist, engine_device="cpu",
-                       slice_iterations=8, seed_states_per_rank=4, low_water=4)
+                       **dict(dict(slice_iterations=8, seed_states_per_rank=4, low_water=4), **(options or {})))
     root = torch.from_numpy(om.domains()).unsqueeze(0).contiguous()
     local, totals = sh.run(root)
+    assert sh.seconds["total"] >= sh.seconds["busy"] > 0 and 0.0 <= sh.idle_fraction() <= 1.0
     out_q.put((rank, local["nodes"], local["solutions"], totals["nodes"], totals["solutions"], totals["best"],
-               sh.states_moved))
+               sh.states_moved, bool(sh.seeded_alike), sh.early_exchanges))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _run(world, text):
+def _run(world, text, options=None):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, text, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, text, q, options)) for r in range(world)]
     for p in procs:
         p.start()
     try:
@@ -77,17 +78,33 @@ def _run(world, text):
     return res
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 5])
 def test_sharded_all_solutions(world):
-    """queens-8 ALL over 2 and 3 ranks: 92 solutions in total, every rank does part of the work,
-    and the total number of explored nodes equals the single-engine tree."""
+    """queens-8 ALL over 2, 3 and 5 ranks: 92 solutions in total, every rank does part of the work, every rank
+    computed the same seed frontier by itself, and the total number of explored nodes equals the single-engine
+    tree (the common seeding phase counted once)."""
     from csolve_amd import problems
     res = _run(world, problems.queens(8, "ALL"))
     assert all(r[4] == 92 for r in res)
     assert sum(r[2] for r in res) == 92
     assert all(r[1] > 0 for r in res), "a rank stayed idle"
+    assert all(r[7] for r in res), "the ranks' seed frontiers differed"
     single = _run(1, problems.queens(8, "ALL"))
     assert res[0][3] == single[0][3]
+
+
+def test_sharded_search_without_the_page_and_with_rank0_seeding():
+    """the fallbacks: no shared status page (ranks on different nodes) and the frontier broadcast from rank 0;
+    long slices with the page: a dry rank calls the exchange before the slice is used up"""
+    from csolve_amd import problems
+    text = problems.queens(8, "ALL")
+    single = _run(1, text)
+    res = _run(3, text, dict(status_page=False, seed_on_every_rank=False))
+    assert all(r[4] == 92 for r in res) and res[0][3] == single[0][3] and not any(r[7] for r in res)
+    assert all(r[8] == 0 for r in res)
+    res = _run(3, text, dict(slice_iterations=1 << 20, poll_iterations=2))
+    assert all(r[4] == 92 for r in res) and res[0][3] == single[0][3]
+    assert sum(r[8] for r in res) > 0, "nobody answered a dry rank's call"
 
 
 def test_sharded_minimisation_shares_the_incumbent():

@@ -2,6 +2,7 @@
 validity against the goldens of the compiled reference (tests/golden/solve_stats.json) and
 the oracle."""
 import json
+import os
 
 import numpy as np
 import pytest
@@ -335,3 +336,48 @@ def test_a_shared_incumbent_survives_its_owner_and_refuses_to_be_decoupled():
     a.close()
     b.close()
     torch.cuda.synchronize()
+
+
+def _bench_search(extra, ranks=1, timeout=420):
+    """bench.py --workload search in child processes (the process group lives and dies with them) -> the JSON line"""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable]
+    if ranks > 1:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
+                "--master-port", str(port)]
+    cmd += [os.path.join(ROOT, "bench.py"), "--workload", "search", "--gpus", str(ranks), "--steps", "1", "--warmup", "0"] + extra
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    return json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+def test_the_coordinator_runs_over_rccl_with_device_tensors():
+    """the `nccl` branch of ShardedSearch with a world of one rank: all_gather_into_tensor / all_reduce on device
+    tensors through RCCL, the same walk as without a process group, per-rank clocks in the bench record"""
+    rec = _bench_search(["--search-queens", "10", "--process-group", "--comm", "nccl"])
+    assert rec["config"]["process_group"] == "nccl" and rec["config"]["solutions"] == 724
+    plain = _bench_search(["--search-queens", "10"])
+    assert plain["config"]["process_group"] is None
+    assert (plain["config"]["nodes"], plain["config"]["cuts"]) == (rec["config"]["nodes"], rec["config"]["cuts"])
+    r = rec["ranks"][0]
+    assert 0.0 <= r["idle_fraction"] < 1.0 and r["busy_seconds"] > 0 and r["put_states"] >= 1
+
+
+def test_four_ranks_on_one_gpu_walk_the_single_engine_tree():
+    """four ranks sharing cuda:0 (gloo, host tensors between them): the status page is in use, every rank seeded
+    itself, the totals equal the one-rank tree, and the cost of rebuilding forbidden sets of seeded and stolen
+    states is a small part of a rank's time"""
+    one = _bench_search(["--search-queens", "12"])
+    rec = _bench_search(["--search-queens", "12", "--comm", "gloo", "--same-device"], ranks=4)
+    assert rec["config"]["solutions"] == one["config"]["solutions"] == 14200
+    assert (rec["config"]["nodes"], rec["config"]["cuts"]) == (one["config"]["nodes"], one["config"]["cuts"])
+    assert len(rec["ranks"]) == 4 and all(n > 0 for n in rec["config"]["nodes_per_rank"])
+    assert all(r["put_fraction"] is not None and r["put_fraction"] < 0.05 for r in rec["ranks"]), rec["ranks"]

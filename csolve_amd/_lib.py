@@ -104,6 +104,16 @@ def load_library():
     L.csgpu_search_take.argtypes = [vp, vp, i64, C.POINTER(i64)]
     L.csgpu_search_set_best.argtypes = [vp, i32]
     L.csgpu_search_put_cost.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64)]
+    L.csgpu_objective_better.argtypes = [C.c_int, Val, i32]
+    L.csgpu_objective_bound.argtypes = [C.c_int, Val, i32]
+    L.csgpu_objective_bound.restype = Val
+    L.csgpu_objective_best.argtypes = [C.c_int, Val, i32]
+    L.csgpu_objective_best.restype = i32
+    L.csgpu_luby_next.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.csgpu_luby_next.restype = None
+    L.csgpu_step_check.argtypes = [Val, C.c_uint32]
+    L.csgpu_step_val.argtypes = [Val, C.c_uint32, C.c_uint32]
+    L.csgpu_step_val.restype = i32
     L.csgpu_search_share_incumbent.argtypes = [vp, vp]
     L.csgpu_search_set_parents.argtypes = [vp, i64]
     L.csgpu_search_set_restart.argtypes = [vp, i64]

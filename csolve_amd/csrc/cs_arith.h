@@ -122,4 +122,49 @@ CS_HD static inline cs_val cs_ev_or(cs_val a, cs_val b) {
   return cs_tv(cs_is_true(a) || cs_is_true(b), cs_is_false(a) && cs_is_false(b));
 }
 
+/* ---- helpers of the search driver shared by the device kernels, the engine and the drop-in ------------------
+ * (pinned by the reference's own unit vectors: tests/golden/ref_unit_objective.json, ref_unit_search.json) */
+
+/* objective_better (objective.c:62-78): can a node whose objective value is `d` still beat the incumbent?
+ * sense: 0 = ANY / ALL (always), 1 = minimise, 2 = maximise */
+CS_HD static inline int cs_objective_better(int sense, cs_val d, int32_t best) {
+  return sense == 1 ? d.lo < best : (sense == 2 ? d.hi > best : 1);
+}
+
+/* objective_update_val (objective.c:101-126): the objective value under the incumbent bound */
+CS_HD static inline cs_val cs_objective_bound(int sense, cs_val d, int32_t best) {
+  if (sense == 1) {
+    const int32_t h = cs_add(best, cs_neg(1));
+    if (d.hi > h) d.hi = h;
+  } else if (sense == 2) {
+    const int32_t l = cs_add(best, 1);
+    if (d.lo < l) d.lo = l;
+  }
+  return d;
+}
+
+/* objective_update_best (objective.c:81-98): the incumbent after a solution with objective value `d` */
+CS_HD static inline int32_t cs_objective_best(int sense, cs_val d, int32_t best) {
+  return sense == 1 ? d.lo : (sense == 2 ? d.hi : best);
+}
+
+/* fail_threshold_next (csolve.c:76-83): Knuth's formulation of the Luby sequence 1 1 2 1 1 2 4 ... */
+static inline void cs_luby_next(uint64_t *threshold, uint64_t *counter) {
+  if ((*counter & (0 - *counter)) == *threshold) {
+    (*counter)++;
+    *threshold = 1;
+  } else {
+    *threshold <<= 1;
+  }
+}
+
+/* step_check / step_val (csolve.c:323-338): iteration `iter` of a variable with the interval `bounds` is valid
+ * while iter <= hi - lo; its value walks in from the edges, the parity of `seed` deciding which edge is first */
+CS_HD static inline int cs_step_check(cs_val bounds, uint32_t iter) {
+  return iter <= (uint32_t)bounds.hi - (uint32_t)bounds.lo;
+}
+CS_HD static inline int32_t cs_step_val(cs_val bounds, uint32_t iter, uint32_t seed) {
+  return ((iter ^ seed) & 1u) ? (int32_t)((uint32_t)bounds.hi - (iter >> 1)) : (int32_t)((uint32_t)bounds.lo + (iter >> 1));
+}
+
 #endif /* CS_ARITH_H */

@@ -103,6 +103,34 @@ extern "C" int csgpu_set_device(int device) {
   return CSGPU_OK;
 }
 
+/* ---- helpers of the search driver (cs_arith.h), exported so that the reference's unit vectors run against the
+ * very functions the kernels, the engine and the drop-in use ---------------------------------------------------- */
+
+static int objective_sense(int objective) { return objective == CS_OBJ_MIN ? 1 : (objective == CS_OBJ_MAX ? 2 : 0); }
+
+extern "C" int csgpu_objective_better(int objective, csgpu_val value, int32_t best) {
+  return cs_objective_better(objective_sense(objective), cs_interval(value.lo, value.hi), best);
+}
+extern "C" csgpu_val csgpu_objective_bound(int objective, csgpu_val value, int32_t best) {
+  const cs_val v = cs_objective_bound(objective_sense(objective), cs_interval(value.lo, value.hi), best);
+  csgpu_val out;
+  out.lo = v.lo;
+  out.hi = v.hi;
+  return out;
+}
+extern "C" int32_t csgpu_objective_best(int objective, csgpu_val value, int32_t best) {
+  return cs_objective_best(objective_sense(objective), cs_interval(value.lo, value.hi), best);
+}
+extern "C" void csgpu_luby_next(uint64_t *threshold, uint64_t *counter) {
+  if (threshold != NULL && counter != NULL) cs_luby_next(threshold, counter);
+}
+extern "C" int csgpu_step_check(csgpu_val bounds, uint32_t iter) {
+  return cs_step_check(cs_interval(bounds.lo, bounds.hi), iter);
+}
+extern "C" int32_t csgpu_step_val(csgpu_val bounds, uint32_t iter, uint32_t seed) {
+  return cs_step_val(cs_interval(bounds.lo, bounds.hi), iter, seed);
+}
+
 /* ---- host model ------------------------------------------------------------------ */
 
 static int wrap_model(cs_model *host, int from_dump, csgpu_model **out) {

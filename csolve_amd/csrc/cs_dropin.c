@@ -463,8 +463,8 @@ static prop_result_t propagate_clauses_timed(const struct clause_list_t *clauses
       int found = -1;
       for (int j = 0; j < want; j++) {
         const int it = g_sib.next_iter + j;
-        const int from_lo = ((it & 1) == 0) == (g_sib.first_is_lo != 0);
-        g_sib.values[j] = from_lo ? g_sib.lo + (it >> 1) : g_sib.hi - (it >> 1);
+        /* the parity of the driver's seed is known from the first value it asked for */
+        g_sib.values[j] = cs_step_val(cs_interval(g_sib.lo, g_sib.hi), (uint32_t)it, g_sib.first_is_lo ? 0u : 1u);
         if (g_sib.values[j] == k) found = j;
       }
       if (found >= 0) {

@@ -468,9 +468,9 @@ __global__ __launch_bounds__(CS_BLOCK) void cs_propagate_events(cs_tables T, con
       cs_val d = dom[T.obj_var];
       int obj_lo = T.obj_lo, obj_hi = T.obj_hi;
       if (T.obj_best_dev != nullptr) {
-        const int best = *T.obj_best_dev;
-        if (T.obj_sense == 1) obj_hi = cs_add(best, cs_neg(1));
-        else obj_lo = cs_add(best, 1);
+        const cs_val lim = cs_objective_bound(T.obj_sense, cs_interval(obj_lo, obj_hi), *T.obj_best_dev);
+        obj_lo = lim.lo;
+        obj_hi = lim.hi;
       }
       const int nl = cs_max(d.lo, obj_lo), nh = cs_min(d.hi, obj_hi);
       if (nl != d.lo || nh != d.hi) {
@@ -595,9 +595,9 @@ __global__ __launch_bounds__(CS_BLOCK) void cs_propagate_clause_rounds(cs_tables
       if (T.obj_var >= 0) { /* untrailed tightening of "<obj>" by the incumbent (objective.c:101-126) */
         int obj_lo = T.obj_lo, obj_hi = T.obj_hi;
         if (T.obj_best_dev != nullptr) {
-          const int best = *T.obj_best_dev;
-          if (T.obj_sense == 1) obj_hi = cs_add(best, cs_neg(1));
-          else obj_lo = cs_add(best, 1);
+          const cs_val lim = cs_objective_bound(T.obj_sense, cs_interval(obj_lo, obj_hi), *T.obj_best_dev);
+          obj_lo = lim.lo;
+          obj_hi = lim.hi;
         }
         const cs_val d = dom[T.obj_var];
         dom[T.obj_var] = cs_interval(cs_max(d.lo, obj_lo), cs_min(d.hi, obj_hi));

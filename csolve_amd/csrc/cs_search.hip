@@ -1283,9 +1283,9 @@ static int one_iteration(csgpu_search *s) {
   const unsigned scramble =
       s->objective == CS_OBJ_ANY ? (unsigned)(s->st.iterations * 2654435761ull + 0x9e3779b9u) | 1u : 0u;
   /* the incumbent tightens "<obj>" for every child (objective.c:101-126) */
-  int32_t obj_lo = CS_DOM_MIN, obj_hi = CS_DOM_MAX;
-  if (s->objective == CS_OBJ_MIN) obj_hi = cs_add(s->st.best, cs_neg(1));
-  if (s->objective == CS_OBJ_MAX) obj_lo = cs_add(s->st.best, 1);
+  const int sense = s->objective == CS_OBJ_MIN ? 1 : (s->objective == CS_OBJ_MAX ? 2 : 0);
+  cs_val lim = cs_objective_bound(sense, cs_interval(CS_DOM_MIN, CS_DOM_MAX), s->st.best);
+  int32_t obj_lo = lim.lo, obj_hi = lim.hi;
   unsigned long long skipped_now = 0; /* large path: children cut without a launch, known with the child count */
   int64_t children;          /* what the launches are sized for */
   const uint64_t *d_children; /* where the real count is, when the host does not know it yet */
@@ -1342,8 +1342,9 @@ static int one_iteration(csgpu_search *s) {
       hipLaunchKernelGGL(cs_emit<64>, dim3(pb), dim3(SB), 0, 0, first_row, (int)parents, (const cs_choice *)s->d_choice,
                          (const int *)s->d_child_off, s->d_nodes, low_last, scramble);
     /* the incumbent may just have improved */
-    if (s->objective == CS_OBJ_MIN) obj_hi = cs_add(s->st.best, cs_neg(1));
-    if (s->objective == CS_OBJ_MAX) obj_lo = cs_add(s->st.best, 1);
+    lim = cs_objective_bound(sense, cs_interval(CS_DOM_MIN, CS_DOM_MAX), s->st.best);
+    obj_lo = lim.lo;
+    obj_hi = lim.hi;
   }
   s->top -= parents;
   s->st.iterations++;
@@ -1579,12 +1580,7 @@ extern "C" int csgpu_search_run(csgpu_search *s, int64_t max_iterations, csgpu_s
     if (restarts_on && s->st.solutions == 0 &&
         (s->since_restart += steps) > (int64_t)s->luby_threshold * s->restart_base) {
       s->since_restart = 0;
-      if ((s->luby_counter & (0 - s->luby_counter)) == s->luby_threshold) {
-        s->luby_counter++;
-        s->luby_threshold = 1;
-      } else {
-        s->luby_threshold <<= 1;
-      }
+      cs_luby_next(&s->luby_threshold, &s->luby_counter);
       s->st.restarts++;
       s->top = 0;
       const int64_t keep = s->restart_base; /* do not record the re-seeding as new seeds */

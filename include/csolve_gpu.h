@@ -267,6 +267,23 @@ int csgpu_search_set_restart(csgpu_search *s, int64_t iterations);
 /* host time csgpu_search_put / put_host have taken since the last reset (device copy + rebuilding the forbidden
  * sets of the arriving states, which travel between ranks without them) and the states they brought */
 int csgpu_search_put_cost(const csgpu_search *s, double *seconds, int64_t *states);
+/* ---- helpers of the search driver -----------------------------------------------------------------------------
+ * Host functions, no device needed.  The same code (csolve_amd/csrc/cs_arith.h) runs inside the kernels
+ * (incumbent bound), the engine (restart schedule) and the drop-in (order of sibling values); exported so the
+ * reference's unit vectors (test/test_objective.c, test/test_csolve.c:305-337,628-657) can be run against it.
+ * `objective`: as returned by csgpu_model_objective (0 ANY 1 ALL 2 MIN 3 MAX). */
+/* objective_better (objective.c:62-78): can objective value `value` still beat the incumbent `best`? */
+int csgpu_objective_better(int objective, csgpu_val value, int32_t best);
+/* objective_update_val (objective.c:101-126): `value` under the incumbent bound (MIN: hi <= best - 1) */
+csgpu_val csgpu_objective_bound(int objective, csgpu_val value, int32_t best);
+/* objective_update_best (objective.c:81-98): the incumbent after a solution with objective value `value` */
+int32_t csgpu_objective_best(int objective, csgpu_val value, int32_t best);
+/* fail_threshold_next (csolve.c:76-83): the next element of the Luby sequence 1 1 2 1 1 2 4 ... */
+void csgpu_luby_next(uint64_t *threshold, uint64_t *counter);
+/* step_check / step_val (csolve.c:323-338): is iteration `iter` over `bounds` valid, and the value it tries */
+int csgpu_step_check(csgpu_val bounds, uint32_t iter);
+int32_t csgpu_step_val(csgpu_val bounds, uint32_t iter, uint32_t seed);
+
 /* merge an incumbent found elsewhere (objective_best of the shared page, objective.c:89-93) */
 int csgpu_search_set_best(csgpu_search *s, int32_t best);
 /* MIN / MAX engines of the same model on one device: from now on `s` keeps its incumbent in `with`'s word of

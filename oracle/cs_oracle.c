@@ -217,6 +217,40 @@ static void heap_update(cso *o, int32_t v) { /* strategy.c:240-246 */
   }
 }
 
+/* test hooks: the reference's own unit vectors of strategy.c (tests/golden/ref_unit_strategy.json) are run
+ * against the comparison and the heap above.  op: 0 up(a), 1 down(a), 2 swap(a, b), 3 push(var a), 4 pop -> var,
+ * 5 update(var a) */
+void cso_test_set_strategy(cso *o, int order_kind, int prefer_failing) {
+  o->order_kind = order_kind;
+  o->prefer_failing = prefer_failing;
+}
+void cso_test_set_prio(cso *o, int32_t var, int64_t prio) { o->prio[var] = prio; }
+int cso_test_var_cmp(const cso *o, int32_t v1, int32_t v2) { return var_cmp(o, v1, v2); }
+void cso_test_heap_load(cso *o, const int32_t *vars, int32_t n) {
+  for (int32_t v = 0; v < o->m->n_vars; v++) o->order[v] = -1;
+  o->heap_n = n;
+  for (int32_t i = 0; i < n; i++) {
+    o->heap[i] = vars[i];
+    o->order[vars[i]] = i;
+  }
+}
+int32_t cso_test_heap_op(cso *o, int op, int32_t a, int32_t b) {
+  switch (op) {
+  case 0: heap_up(o, a); return 0;
+  case 1: heap_down(o, a); return 0;
+  case 2: heap_swap(o, a, b); return 0;
+  case 3: heap_push(o, a); return 0;
+  case 4: return heap_pop(o);
+  case 5: heap_update(o, a); return 0;
+  default: return -1;
+  }
+}
+int32_t cso_test_heap_get(const cso *o, int32_t *out) {
+  for (int32_t i = 0; i < o->heap_n; i++) out[i] = o->heap[i];
+  return o->heap_n;
+}
+int32_t cso_test_heap_pos(const cso *o, int32_t var) { return o->order[var]; }
+
 /* ---- evaluation (eval.c) --------------------------------------------------- */
 
 static cs_val ev(cso *o, int32_t node);

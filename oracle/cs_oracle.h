@@ -49,6 +49,14 @@ void cso_set_root_phase(cso *o, int on);
 /* record_only = 1 reproduces the reference unit tests' mocked bind(): a narrowing is
  * logged and counted as 1 but the domain is left unchanged (test/test_propagate.c:52-54). */
 void cso_set_record_only(cso *o, int on);
+/* test hooks for the reference's strategy.c unit vectors (see cs_oracle.c) */
+void cso_test_set_strategy(cso *o, int order_kind, int prefer_failing);
+void cso_test_set_prio(cso *o, int32_t var, int64_t prio);
+int cso_test_var_cmp(const cso *o, int32_t v1, int32_t v2);
+void cso_test_heap_load(cso *o, const int32_t *vars, int32_t n);
+int32_t cso_test_heap_op(cso *o, int op, int32_t a, int32_t b);
+int32_t cso_test_heap_get(const cso *o, int32_t *out);
+int32_t cso_test_heap_pos(const cso *o, int32_t var);
 
 cs_val *cso_domains(cso *o); /* [n_vars], live */
 uint64_t cso_props(const cso *o);

@@ -38,7 +38,9 @@ class Result(C.Structure):
 
 def build(force: bool = False) -> str:
     """Compile liboracle.so with gcc (a few seconds)."""
-    if force or not os.path.exists(_LIB_PATH):
+    stale = not os.path.exists(_LIB_PATH) or any(
+        os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH) for f in ("cs_oracle.c", "cs_oracle.h"))
+    if force or stale:
         subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
     return _LIB_PATH
 
@@ -107,6 +109,16 @@ def lib():
         L.cso_instance.argtypes = [vp, vp, i32, Val, vp]
         L.cso_instances.restype = u64
         L.cso_instances.argtypes = [vp, vp, vp, i64, vp, vp]
+        L.cso_test_set_strategy.argtypes = [vp, C.c_int, C.c_int]
+        L.cso_test_set_prio.argtypes = [vp, i32, i64]
+        L.cso_test_var_cmp.argtypes = [vp, i32, i32]
+        L.cso_test_heap_load.argtypes = [vp, C.POINTER(i32), i32]
+        L.cso_test_heap_op.restype = i32
+        L.cso_test_heap_op.argtypes = [vp, C.c_int, i32, i32]
+        L.cso_test_heap_get.restype = i32
+        L.cso_test_heap_get.argtypes = [vp, C.POINTER(i32)]
+        L.cso_test_heap_pos.restype = i32
+        L.cso_test_heap_pos.argtypes = [vp, i32]
         L.cso_default_options.argtypes = [C.POINTER(Options)]
         L.cso_solve.argtypes = [vp, C.POINTER(Options), C.POINTER(Result)]
         L.cso_result_free.argtypes = [C.POINTER(Result)]

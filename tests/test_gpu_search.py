@@ -381,3 +381,50 @@ def test_four_ranks_on_one_gpu_walk_the_single_engine_tree():
     assert (rec["config"]["nodes"], rec["config"]["cuts"]) == (one["config"]["nodes"], one["config"]["cuts"])
     assert len(rec["ranks"]) == 4 and all(n > 0 for n in rec["config"]["nodes_per_rank"])
     assert all(r["put_fraction"] is not None and r["put_fraction"] < 0.05 for r in rec["ranks"]), rec["ranks"]
+
+
+def test_the_engine_applies_the_incumbent_like_the_reference_unit_vectors():
+    """test/test_objective.c ObjectiveBetter / ObjectiveUpdateVal / ObjectiveUpdateBest on the device: an engine
+    given the incumbent `best` expands a node whose objective variable is `val`; children survive with the
+    tightened objective interval exactly when objective_better() holds, and a solution updates the incumbent"""
+    from csolve_amd.solver import Search, solve_root
+    cases = json.load(open(golden("ref_unit_objective.json")))["cases"]
+    checked = 0
+    for c in cases:
+        if c.get("objective") not in ("MIN", "MAX") or c["fn"] not in ("better", "update_val") or c["val"] is None:
+            continue
+        lo, hi = c["val"]
+        # the objective variable x with the vector's interval and a free 0/1 variable to branch on
+        model = solve_root(f"{c['objective']} x; {lo} <= x; x <= {hi}; 0 <= y; y <= 1;")
+        s = Search(model, 1 << 10, 1 << 8)
+        s.put(model.root_state())
+        s.set_best(c["best"])
+        st = s.run(1)
+        from csolve_amd import _lib
+        b = _lib.load_library().csgpu_objective_bound(model.objective, _lib.Val(lo, hi), c["best"])
+        better = c["expect"] if c["fn"] == "better" else b.lo <= b.hi
+        if c["fn"] == "update_val":
+            assert [b.lo, b.hi] == c["expect_val"]
+        if better and lo == hi:  # the children are complete assignments: solutions, and the incumbent moves
+            assert st["solutions"] >= 1 and st["best"] == lo and st["cuts"] == 0, (c, st)
+        elif better:
+            kids = s.take(4).cpu().numpy()
+            assert kids.shape[0] == 2 and st["cuts"] == 0, (c, st)
+            ov = model.objective_var
+            got = sorted([int(k[ov, 0]), int(k[ov, 1])] for k in kids)
+            # branched on y: both children carry the bounded interval; branched on x itself (a tie of two-value
+            # intervals goes to the lower index): the children are the values of the bounded interval
+            assert got == [[b.lo, b.hi]] * 2 or (b.hi - b.lo == 1 and got == [[b.lo, b.lo], [b.hi, b.hi]]), (c, got)
+        else:
+            assert st["pool"] == 0 and st["cuts"] == 2, (c, st)
+        checked += 1
+        s.close()
+    assert checked >= 20
+    # ObjectiveUpdateBest: the incumbent after the first solution is the objective's lower (MIN) / upper (MAX) bound
+    for text, best in (("MIN x; -17 <= x; x <= 5;", -17), ("MAX x; -3 <= x; x <= 17;", 17)):
+        model = solve_root(text)
+        s = Search(model, 1 << 10, 1 << 8)
+        s.put(model.root_state())
+        st = s.run()
+        assert st["done"] == 1 and st["best"] == best
+        s.close()

@@ -3,13 +3,14 @@ declares, the front end and the clause index replay the reference (checked again
 reference's own post-root dumps), the device tables classify clauses as documented.
 No compute call is made here (there is no GPU in this tier)."""
 import ctypes as C
+import json
 import os
 
 import numpy as np
 import pytest
 
 from conftest import golden
-from oracle.cs_oracle import Model as OModel, Oracle, lib as olib
+from oracle.cs_oracle import OPS, Model as OModel, Oracle, lib as olib
 
 MODELS = ["queens4", "queens8", "queens16", "queens64", "ref_sudoku", "sudoku9_s7", "ref_schedule", "ref_wcet",
           "schedule6_s1"]
@@ -165,3 +166,130 @@ def test_front_end_plus_normaliser_reproduce_the_reference_trees(name):
     mine.index()
     ok, why = mine.equal(ref)
     assert ok, why
+
+
+# ---- the reference's own unit vectors for the "next" rows: normaliser ------------------------------
+
+def _normalize_cases():
+    return json.load(open(golden("ref_unit_normalize.json")))["cases"]
+
+
+class _Tree:
+    """hand-made model for one vector of tests/golden/ref_unit_normalize.json"""
+
+    def __init__(self, terms):
+        self.m = OModel.empty()
+        self.term = {}
+        for name, (lo, hi) in terms.items():
+            self.term[name] = self.m.add_const(lo) if lo == hi else self.m.var_node(self.m.add_var(name, lo, hi))
+
+    def build(self, e):
+        if isinstance(e, str):
+            return self.term[e]
+        if e[0] == "CONST":
+            return self.m.add_const(e[1])
+        kids = [self.build(k) for k in e[1:]]
+        return self.m.add_node(e[0], kids[0], kids[1] if len(kids) > 1 else -1)
+
+    def node(self, i):
+        v = self.m.view
+        return v.nodes[3 * i], v.nodes[3 * i + 1], v.nodes[3 * i + 2]
+
+    def matches(self, i, e):
+        """structure of node i == expected expression e (terminals by identity, created constants by value)"""
+        op, a, b = self.node(i)
+        if isinstance(e, str):
+            t = self.term[e]
+            return i == t or (op == OPS["CONST"] and self.node(t)[0] == OPS["CONST"] and self.node(t)[1:] == (a, b))
+        if e[0] == "CONST":
+            return op == OPS["CONST"] and (a, b) == (e[1], e[1])
+        if op != OPS[e[0]]:
+            return False
+        return self.matches(a, e[1]) and (len(e) < 3 or self.matches(b, e[2]))
+
+    def show(self, i):
+        op, a, b = self.node(i)
+        name = [k for k, v in OPS.items() if v == op][0]
+        if name == "VAR":
+            return self.m.names()[a]
+        if name == "CONST":
+            return str(a)
+        return "(" + name + " " + self.show(a) + ("" if b < 0 else " " + self.show(b)) + ")"
+
+
+@pytest.mark.parametrize("case", _normalize_cases(), ids=lambda c: c["ref"].split(" ", 1)[1].replace(" ", "_"))
+def test_normaliser_against_the_reference_unit_vectors(case):
+    """csolve_amd/csrc/cs_normalize.c on the expressions of the reference's test/test_normalize.c: the result has
+    the structure the gtest case expects, and where the gtest expects its argument back no node is created."""
+    t = _Tree(case["terms"])
+    elems = [t.build(e) for e in (case["wand"] if "wand" in case else [case["in"]])]
+    root = t.m.add_wand(elems)
+    t.m.set_root(root)
+    nodes_before = t.m.view.n_nodes
+    t.m.normalize()
+    assert t.m.view.root == root, "the wide-and node itself is kept (normalize.c:282-295)"
+    op, off, count = t.node(root)
+    assert count == len(elems)
+    got = [t.m.view.kids[off + i] for i in range(count)]
+    want = case["wand_out"] if "wand" in case else [case["out"]]
+    for g, w, before in zip(got, want, elems):
+        assert t.matches(g, w), f"{case['ref']}: got {t.show(g)}, want {w}"
+        if case.get("same") and "wand" not in case:
+            assert g == before
+    if case.get("same") and "wand" not in case:
+        assert t.m.view.n_nodes == nodes_before, "the reference returns its argument: no allocation"
+    if "wand" in case:
+        created = sum(1 for g, b in zip(got, elems) if g != b)
+        assert t.m.view.n_nodes == nodes_before + created
+
+
+# ---- the reference's unit vectors of the search driver's helpers (objective bound, Luby, value order) ------------
+
+_OBJ = {"ANY": 0, "ALL": 1, "MIN": 2, "MAX": 3}
+
+
+def test_objective_helpers_against_the_reference_unit_vectors():
+    """csgpu_objective_better / _bound / _best -- the functions the kernels and the engine apply the incumbent with
+    (cs_arith.h) -- on the vectors of the reference's test/test_objective.c:79-311"""
+    from csolve_amd import _lib
+    L = _lib.load_library()
+    cases = json.load(open(golden("ref_unit_objective.json")))["cases"]
+    seen = set()
+    for c in cases:
+        v = _lib.Val(*(c["val"] or [0, 0])) if "val" in c else None
+        if c["fn"] == "better":
+            assert bool(L.csgpu_objective_better(_OBJ[c["objective"]], v, c["best"])) == c["expect"], c
+        elif c["fn"] == "update_best":
+            assert L.csgpu_objective_best(_OBJ[c["objective"]], v, c["best"]) == c["expect_best"], c
+        elif c["fn"] == "update_val":
+            out = L.csgpu_objective_bound(_OBJ[c["objective"]], v, c["best"])
+            assert [out.lo, out.hi] == c["expect_val"], c
+        else:
+            assert c["fn"] == "best" and c["best"] == c["expect_best"]  # objective_best() is a plain read
+        seen.add(c["fn"])
+    assert seen == {"better", "update_best", "update_val", "best"} and len(cases) >= 30
+
+
+def test_luby_and_value_order_against_the_reference_unit_vectors():
+    """csgpu_luby_next (the engine's restart schedule) on FailThresholdNext.Basic, csgpu_step_check / _step_val (the
+    drop-in's sibling order) on Step.Check / Step.Val of the reference's test/test_csolve.c"""
+    from csolve_amd import _lib
+    L = _lib.load_library()
+    d = json.load(open(golden("ref_unit_search.json")))
+    thr, cnt = C.c_uint64(d["luby"]["threshold"]), C.c_uint64(d["luby"]["counter"])
+    got = [thr.value]
+    for _ in d["luby"]["thresholds"][1:]:
+        L.csgpu_luby_next(C.byref(thr), C.byref(cnt))
+        got.append(thr.value)
+    assert got == d["luby"]["thresholds"] == [1, 1, 2, 1, 1, 2, 4, 1, 1, 2, 1, 1, 2, 4, 8]
+    b = _lib.Val(*d["step_check"]["bounds"])
+    for row in d["step_check"]["rows"]:
+        assert bool(L.csgpu_step_check(b, row["iter"])) == row["expect"], row
+    b = _lib.Val(*d["step_val"]["bounds"])
+    for seed in (0, 1, 12345):
+        vals = [L.csgpu_step_val(b, row["iter"], seed) for row in d["step_val"]["rows"]]
+        assert all(b.lo <= v <= b.hi for v in vals) and vals[0] != vals[1]
+    # csolve.c:331-338 in full: from the edges inwards, every value of the interval exactly once
+    walk = [L.csgpu_step_val(b, i, 0) for i in range(b.hi - b.lo + 1)]
+    assert walk[:4] == [3, 17, 4, 16] and sorted(walk) == list(range(3, 18))
+    assert [L.csgpu_step_val(b, i, 1) for i in range(4)] == [17, 3, 16, 4]

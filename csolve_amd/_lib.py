@@ -103,6 +103,7 @@ def load_library():
     L.csgpu_search_put_host.argtypes = [vp, vp, i64]
     L.csgpu_search_take.argtypes = [vp, vp, i64, C.POINTER(i64)]
     L.csgpu_search_set_best.argtypes = [vp, i32]
+    L.csgpu_model_add_conflict.argtypes = [vp, i32, vp, vp]
     L.csgpu_search_put_cost.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64)]
     L.csgpu_objective_better.argtypes = [C.c_int, Val, i32]
     L.csgpu_objective_bound.argtypes = [C.c_int, Val, i32]
@@ -122,6 +123,7 @@ def load_library():
     L.csgpu_search_best_solution.argtypes = [vp, vp]
     L.csgpu_search_solutions.restype = i64
     L.csgpu_propagate_one.argtypes = [vp, vp, Node, vp, C.POINTER(Result)]
+    L.csgpu_propagate_one_traced.argtypes = [vp, vp, Node, vp, C.POINTER(Result), vp, i32, C.POINTER(i32)]
     L.csgpu_propagate_values.argtypes = [vp, vp, i32, vp, i32, vp, vp]
     L.csgpu_model_root_propagate_limit.argtypes = [vp, i64, C.POINTER(i32), C.POINTER(i32)]
     _lib = L

@@ -81,6 +81,12 @@ struct csgpu_model {
   /* pinned host memory mapped into the device's address space: the kernel reads the state and the node record
    * from it and writes the result and the new state back, no staging copies */
   unsigned char *h_one;          /* [state | node | result | state_out] */
+  /* csgpu_propagate_one_traced: clause of every adjacency entry (device), the log and its counter (mapped host
+   * memory), allocated at the first traced call */
+  int *d_adj_clause;
+  int32_t *h_trace;
+  unsigned *h_trace_n;
+  int trace_cap;
   cs_val *d_one_in, *d_one_out;  /* device views of the four parts */
   cs_node_in *d_one_node;
   cs_node_out *d_one_res;
@@ -215,6 +221,12 @@ static void free_device(csgpu_model *m) {
   m->fb_words = 0;
   (void)hipHostFree(m->h_one);
   m->h_one = NULL;
+  (void)hipFree(m->d_adj_clause);
+  m->d_adj_clause = NULL;
+  if (m->h_trace != NULL) (void)hipHostFree(m->h_trace);
+  m->h_trace = NULL;
+  m->h_trace_n = NULL;
+  m->trace_cap = 0;
   if (m->h_values != NULL) (void)hipHostFree(m->h_values);
   m->h_values = m->d_values = NULL;
   m->values_cap = 0;
@@ -388,6 +400,27 @@ extern "C" int csgpu_model_normalize(csgpu_model *m) {
   if (m->finalized) return set_err(CSGPU_E_STATE, "model is already finalized");
   if (cs_model_normalize(m->host) < 0) return set_err(CSGPU_E_STATE, "model has no root");
   return CSGPU_OK;
+}
+
+extern "C" int csgpu_model_add_conflict(csgpu_model *m, int32_t count, const int32_t *vars, const int32_t *values) {
+  if (m == NULL || count < 1 || vars == NULL || values == NULL) return set_err(CSGPU_E_ARG, "bad argument");
+  cs_model *h = m->host;
+  if (h->root < 0) return set_err(CSGPU_E_STATE, "model has no root");
+  if (count + 1 > CS_MAX_TREE_NODES) return set_err(CSGPU_E_LIMIT, "a conflict of %d elements, device limit is %d", count, CS_MAX_TREE_NODES - 1);
+  int32_t *terms = (int32_t *)malloc((size_t)count * sizeof(int32_t));
+  for (int32_t i = 0; i < count; i++) {
+    if (vars[i] < 0 || vars[i] >= h->n_vars) {
+      free(terms);
+      return set_err(CSGPU_E_ARG, "conflict element %d: no such variable", i);
+    }
+    terms[i] = h->var_node[vars[i]];
+  }
+  const int32_t node = cs_model_add_confl(h, terms, values, count);
+  free(terms);
+  if (cs_model_append_clause(h, node) != 0) return set_err(CSGPU_E_ARG, "conflict clause could not be indexed");
+  /* the device tables are immutable images: a finalized model is finalized again (O(model) per clause; learnt
+   * clauses arrive once per failed node of a host-driven search, which costs a launch and a round trip anyway) */
+  return m->finalized ? csgpu_model_finalize(m) : CSGPU_OK;
 }
 
 extern "C" int csgpu_model_eval_clauses_host(csgpu_model *m, csgpu_val *vals) {
@@ -1270,6 +1303,56 @@ extern "C" int csgpu_propagate_values(const csgpu_model *cm, const csgpu_val *st
   HIP_TRY(hipStreamSynchronize(NULL));
   memcpy(results, m->h_values + off_res, (size_t)count * sizeof *results);
   memcpy(states_out, m->h_values + off_out, (size_t)count * row);
+  return CSGPU_OK;
+}
+
+/* One node with its trail.  The general kernel (one wave) records every narrowing with the clause that made
+ * it -- what the reference's bind() keeps as binding_t.clause (csolve.h:73-79) and its conflict analysis walks
+ * (conflict.c:290-316) -- and the point of failure. */
+extern "C" int csgpu_propagate_one_traced(const csgpu_model *cm, const csgpu_val *state, csgpu_node node,
+                                          csgpu_val *state_out, csgpu_result *result, int32_t *trace, int32_t cap,
+                                          int32_t *count) {
+  csgpu_model *m = const_cast<csgpu_model *>(cm);
+  if (m == NULL || state == NULL || state_out == NULL || result == NULL || trace == NULL || cap < 1 || count == NULL)
+    return set_err(CSGPU_E_ARG, "bad argument");
+  if (!m->finalized) return set_err(CSGPU_E_STATE, "model is not finalized");
+  if (m->d_adj_clause == NULL) {
+    int rc = upload(m->img->adj_clause, (size_t)(m->img->n_adj ? m->img->n_adj : 1) * 4, &m->d_adj_clause);
+    if (rc != CSGPU_OK) return rc;
+  }
+  if (m->trace_cap < cap) {
+    if (m->h_trace != NULL) (void)hipHostFree(m->h_trace);
+    m->h_trace = NULL;
+    HIP_TRY(hipHostMalloc((void **)&m->h_trace, (size_t)cap * 16 + 16, hipHostMallocMapped));
+    m->h_trace_n = (unsigned *)(m->h_trace + (size_t)cap * 4);
+    m->trace_cap = cap;
+  }
+  const size_t nbytes = (size_t)m->host->n_vars * sizeof(cs_val);
+  const size_t part = (nbytes + 63) & ~(size_t)63;
+  node.parent = 0;
+  memcpy(m->h_one, state, nbytes);
+  memcpy(m->h_one + part, &node, sizeof node);
+  *m->h_trace_n = 0u;
+  cs_tables tab = m->tab;
+  tab.adj_clause = m->d_adj_clause;
+  void *dev = NULL;
+  HIP_TRY(hipHostGetDevicePointer(&dev, m->h_trace, 0));
+  tab.trace_log = (int4 *)dev;
+  tab.trace_n = (unsigned *)((int32_t *)dev + (size_t)cap * 4);
+  tab.trace_cap = (unsigned)cap;
+  const size_t lds = m->slice * CS_WAVES_PER_BLOCK;
+  int rc = lds_limit(lds, (const void *)cs_propagate_events<true, false, true>);
+  if (rc != CSGPU_OK) return rc;
+  hipLaunchKernelGGL((cs_propagate_events<true, false, true>), dim3(1), dim3(CS_BLOCK), lds, 0, tab,
+                     (const cs_val *)m->d_one_in, (const cs_node_in *)m->d_one_node, (cs_val *)m->d_one_out,
+                     (cs_node_out *)m->d_one_res, 1ll, (const unsigned long long *)NULL);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(NULL));
+  memcpy(result, m->h_one + part + 64, sizeof *result);
+  if (result->status >= 0) memcpy(state_out, m->h_one + part + 128, nbytes);
+  const unsigned n = *m->h_trace_n;
+  *count = (int32_t)n;
+  memcpy(trace, m->h_trace, (size_t)(n < (unsigned)cap ? n : (unsigned)cap) * 16);
   return CSGPU_OK;
 }
 

@@ -145,6 +145,19 @@ static int32_t emit_tree(tree_ctx *t, int32_t node) {
     free(loc);
     break;
   }
+  case CS_OP_CONFL: { /* tkid holds the pairs { local index of the terminal, conflict value } */
+    int32_t cnt = n->b, off = n->a;
+    int32_t *loc = (int32_t *)malloc((size_t)(cnt ? cnt : 1) * sizeof(int32_t));
+    for (int32_t i = 0; i < cnt; i++) loc[i] = emit_tree(t, t->m->kids[off + 2 * i]);
+    a = t->tkid.n;
+    for (int32_t i = 0; i < cnt; i++) {
+      ibuf_push(&t->tkid, loc[i]);
+      ibuf_push(&t->tkid, t->m->kids[off + 2 * i + 1]);
+    }
+    b = cnt;
+    free(loc);
+    break;
+  }
   default:
     t->bad = 1;
     break;
@@ -161,7 +174,7 @@ static int32_t emit_tree(tree_ctx *t, int32_t node) {
 
 void cs_dev_image_free(cs_dev_image *g) {
   if (g == NULL) return;
-  free(g->adj_off); free(g->adj); free(g->clause); free(g->tree_off); free(g->tnode); free(g->tkid); free(g->tree_want); free(g->lit); free(g->adj_packed); free(g->sym_off); free(g->sym_packed); free(g->dense_tab);
+  free(g->adj_off); free(g->adj); free(g->adj_clause); free(g->clause); free(g->tree_off); free(g->tnode); free(g->tkid); free(g->tree_want); free(g->lit); free(g->adj_packed); free(g->sym_off); free(g->sym_packed); free(g->dense_tab);
   free(g);
 }
 
@@ -247,7 +260,7 @@ cs_dev_image *cs_dev_image_build(const cs_model *m, int with_lists, const unsign
   free(t.touched.v);
 
   if (t.bad) {
-    if (err) snprintf(err, errlen, "constraint type without a device implementation (conflict clause)");
+    if (err) snprintf(err, errlen, "constraint type without a device implementation");
     cs_dev_image_free(g);
     return NULL;
   }
@@ -260,10 +273,12 @@ cs_dev_image *cs_dev_image_build(const cs_model *m, int with_lists, const unsign
   g->adj_off = (int32_t *)calloc((size_t)m->n_vars + 1, sizeof(int32_t));
   if (with_lists) {
     ibuf adj = { 0 };
+    ibuf adjc = { 0 };
     for (int32_t v = 0; v < m->n_vars; v++) {
       g->adj_off[v] = adj.n / 2;
       for (int32_t i = m->list_off[v]; i < m->list_off[v + 1]; i++) {
         const int32_t *rec = &g->clause[4 * m->list[i]];
+        if (rec[0] != CS_CL_SKIP) ibuf_push(&adjc, m->list[i]);
         if (rec[0] == CS_CL_NE) {
           if (rec[1] == v) { ibuf_push(&adj, rec[2]); ibuf_push(&adj, rec[3]); }
           else { ibuf_push(&adj, rec[1]); ibuf_push(&adj, -rec[3]); }
@@ -285,6 +300,7 @@ cs_dev_image *cs_dev_image_build(const cs_model *m, int with_lists, const unsign
     g->adj_off[m->n_vars] = adj.n / 2;
     g->n_adj = adj.n / 2;
     g->adj = adj.v ? adj.v : (int32_t *)calloc(2, sizeof(int32_t));
+    g->adj_clause = adjc.v ? adjc.v : (int32_t *)calloc(1, sizeof(int32_t));
     /* packed copy for the LDS-resident kernel: only for pure binary-NE adjacency */
     if (g->n_tree_clauses == 0 && g->n_lin == 0 && g->n_or2 == 0 && g->n_adj > 0) {
       int32_t dmin = g->adj[1], dmax = g->adj[1];

@@ -42,7 +42,8 @@
  * Trees.  tree_off[t] .. tree_off[t+1] index tnode[], 4 ints per node { op, a, b, 0 } in
  * post-order (children before parents, the root last); child references are indices local
  * to the tree; VAR: a = variable; CONST: a = lo, b = hi; WAND: a = offset into tkid[],
- * b = count, tkid[] holds local indices.
+ * b = count, tkid[] holds local indices; CONFL (a learnt conflict clause, csolve.h:98-128): a = offset into
+ * tkid[], b = number of elements, tkid[] holds the pairs { local index of the terminal, conflict value }.
  */
 #ifndef CS_DEVICE_H
 #define CS_DEVICE_H
@@ -71,6 +72,7 @@ typedef struct cs_dev_image {
   int32_t max_list;     /* longest per-variable list */
   int32_t *adj_off;     /* [n_vars+1] */
   int32_t *adj;         /* [2*n_adj] */
+  int32_t *adj_clause;  /* [n_adj] the clause behind every adjacency entry (traces) */
   int32_t *clause;      /* [4*n_clauses] */
   int32_t n_trees, n_tnodes, n_tkids, max_tree;
   int32_t *tree_off;    /* [n_trees+1] */

@@ -72,6 +72,12 @@ struct cs_tables {
    * device-driven iterations): sense 1 = minimise (hi = best - 1), 2 = maximise (lo = best + 1) */
   const int *obj_best_dev;
   int obj_sense;
+  /* trace of one node (csgpu_propagate_one_traced; kernel 1 with TRACE only): the clause behind every adjacency
+   * entry, and a log of the narrowings {variable, 0 = lower / 1 = upper bound / 2 = failure, new bound, clause} */
+  const int *adj_clause;
+  int4 *trace_log;
+  unsigned *trace_n;
+  unsigned trace_cap;
 };
 
 struct cs_node_in {
@@ -97,7 +103,23 @@ struct cs_ctx {
   int fail, props, revisions;
   int fail_var; /* a variable whose domain this lane saw become empty (-1: none / not attributable to one variable):
                  * the reference bumps that variable's priority (propagate_term_confl, propagate.c:33-41) */
-  __device__ __forceinline__ void failed_at(int v) { fail = 1; fail_var = v; }
+  /* trace (null unless the kernel was built with TRACE): which clause is being revised, and where narrowings are
+   * recorded -- what the reference keeps as binding_t.clause on its trail (csolve.h:73-79) */
+  int4 *log;
+  unsigned *log_n;
+  unsigned log_cap;
+  int cur_clause;
+  __device__ __forceinline__ void record(int v, int kind, int bound) {
+    if (log != nullptr) {
+      const unsigned i = atomicAdd(log_n, 1u);
+      if (i < log_cap) log[i] = make_int4(v, kind, bound, cur_clause);
+    }
+  }
+  __device__ __forceinline__ void failed_at(int v) {
+    if (!fail) record(v, 2, 0);
+    fail = 1;
+    fail_var = v;
+  }
 
   __device__ __forceinline__ void touched(int v) {
     if (mark_is_flag) mark[0] = 1u;
@@ -107,6 +129,7 @@ struct cs_ctx {
     int old = atomicMax(&dom[v].lo, lo);
     if (old < lo) {
       props++;
+      record(v, 0, lo);
       touched(v);
       if (lo > dom[v].hi) failed_at(v);
     }
@@ -115,6 +138,7 @@ struct cs_ctx {
     int old = atomicMin(&dom[v].hi, hi);
     if (old > hi) {
       props++;
+      record(v, 1, hi);
       touched(v);
       if (hi < dom[v].lo) failed_at(v);
     }
@@ -242,6 +266,19 @@ __device__ inline void cs_tree_eval(const cs_tables &T, const int4 *nd, int len,
         all_true &= cs_is_true(c);
       }
       r = cs_tv(all_true && !any_false, any_false);
+      break;
+    }
+    case CS_OP_CONFL: { /* eval.c:258-277: the first element that is not a value answers "unknown", the first value
+                         * different from its conflict value answers "true" */
+      r = cs_interval(0, 1);
+      for (int i = 0; i < n.z; i++) {
+        const cs_val c = val[T.tkid[n.y + 2 * i]];
+        if (!cs_is_value(c)) break;
+        if (c.lo != T.tkid[n.y + 2 * i + 1]) {
+          r = cs_value(1);
+          break;
+        }
+      }
       break;
     }
     default: r = cs_interval(0, 1); break;
@@ -373,6 +410,24 @@ __device__ inline void cs_tree_revise(const cs_tables &T, int tree, cs_ctx &cx, 
       if (cs_is_true(w))
         for (int i = 0; i < n.z; i++) CS_PUSH(T.tkid[n.y + i], w);
       break;
+    case CS_OP_CONFL: /* propagate.c:395-471 */
+      if (cs_is_true(w)) {
+        /* propagate_confl_find: the one element that is not a value while every other has its conflict value */
+        int p = -1, stop = 0;
+        for (int i = 0; i < n.z && !stop; i++) {
+          const cs_val c = S.val[T.tkid[n.y + 2 * i]];
+          if (cs_is_value(c)) stop = c.lo != T.tkid[n.y + 2 * i + 1];
+          else if (p < 0) p = i;
+          else stop = 1;
+        }
+        if (!stop && p >= 0) { /* propagate_confl_infer: shave the conflict value off the bound it sits on */
+          const int term = T.tkid[n.y + 2 * p], cv = T.tkid[n.y + 2 * p + 1];
+          const cs_val c = S.val[term];
+          if (c.lo == cv && !cs_is_sentinel(c.lo)) CS_PUSH(term, cs_interval(c.lo + 1, CS_DOM_MAX));
+          else if (c.hi == cv && !cs_is_sentinel(c.hi)) CS_PUSH(term, cs_interval(CS_DOM_MIN, c.hi - 1));
+        }
+      }
+      break;
     default:
       break;
     }
@@ -384,7 +439,7 @@ __device__ inline void cs_tree_revise(const cs_tables &T, int tree, cs_ctx &cx, 
 
 /* TAB_LDS: adj_off, adj and lit are copied into LDS by every workgroup (small models: the inner loop then
  * never waits for L2); the per-wave slices follow the tables */
-template <bool HAS_TREE, bool TAB_LDS>
+template <bool HAS_TREE, bool TAB_LDS, bool TRACE = false>
 __global__ __launch_bounds__(CS_BLOCK) void cs_propagate_events(cs_tables T, const cs_val *__restrict__ states_in,
                                                                 const cs_node_in *__restrict__ nodes,
                                                                 cs_val *__restrict__ states_out,
@@ -443,6 +498,13 @@ __global__ __launch_bounds__(CS_BLOCK) void cs_propagate_events(cs_tables T, con
     cs_wave_sync();
 
     cs_ctx cx;
+    cx.log = nullptr;
+    cx.cur_clause = -1;
+    if (TRACE) {
+      cx.log = T.trace_log;
+      cx.log_n = T.trace_n;
+      cx.log_cap = T.trace_cap;
+    }
     cx.dom = dom;
     cx.mark_is_flag = 0;
     cx.fail = 0;
@@ -493,10 +555,14 @@ __global__ __launch_bounds__(CS_BLOCK) void cs_propagate_events(cs_tables T, con
           bits &= bits - 1u;
           /* a variable whose bounds crossed through racing lo/hi updates */
           const cs_val du = dom[u];
-          if (du.lo > du.hi) cx.failed_at(u);
+          if (du.lo > du.hi) {
+            if (TRACE && lane != 0) { cx.fail = 1; cx.fail_var = u; } /* one record for the wave */
+            else cx.failed_at(u);
+          }
           const int beg = TAB_LDS ? s_adj_off[u] : T.adj_off[u], end = TAB_LDS ? s_adj_off[u + 1] : T.adj_off[u + 1];
           for (int i = beg + lane; i < end && !cx.fail; i += CS_WAVE) {
             const int2 e = TAB_LDS ? s_adj[i] : T.adj[i];
+            if (TRACE) cx.cur_clause = T.adj_clause[i];
             if (e.x >= 0) {
               cs_lin_revise(cx, u, e.x & CS_ADJ_VAR_MASK, e.y, e.x >> 28);
             } else if (e.y != 0) {
@@ -606,6 +672,8 @@ __global__ __launch_bounds__(CS_BLOCK) void cs_propagate_clause_rounds(cs_tables
     cs_wave_sync();
 
     cs_ctx cx;
+    cx.log = nullptr;
+    cx.cur_clause = -1;
     cx.dom = dom;
     cx.mark = flag;
     cx.mark_is_flag = 1;
@@ -1755,6 +1823,8 @@ __global__ __launch_bounds__(CS_BLOCK) void cs_propagate_sweeps(cs_tables T, con
   __syncthreads();
 
   cs_ctx cx;
+    cx.log = nullptr;
+    cx.cur_clause = -1;
   cx.dom = dom;
   cx.mark = flags;
   cx.mark_is_flag = 1;

@@ -121,6 +121,17 @@ int32_t cs_model_add_wand(cs_model *m, const int32_t *elems, int32_t n) {
   return cs_model_add_node(m, CS_OP_WAND, off, n);
 }
 
+int32_t cs_model_add_confl(cs_model *m, const int32_t *term_nodes, const int32_t *values, int32_t n) {
+  GROW(m->kids, m->cap_kids, m->n_kids + 2 * n);
+  int32_t off = m->n_kids;
+  for (int32_t i = 0; i < n; i++) {
+    m->kids[off + 2 * i] = term_nodes[i];
+    m->kids[off + 2 * i + 1] = values[i];
+  }
+  m->n_kids += 2 * n;
+  return cs_model_add_node(m, CS_OP_CONFL, off, n);
+}
+
 void cs_model_set_root_from_top(cs_model *m) {
   m->root = cs_model_add_wand(m, m->top, m->n_top);
 }
@@ -270,6 +281,12 @@ static void index_node(index_ctx *c, int32_t node, int32_t clause) {
       n = &c->m->nodes[node];
     }
     break;
+  case CS_OP_CONFL: /* conflict_create appends the clause to the list of every element's variable, conflict.c:356-358 */
+    for (int32_t i = 0; i < n->b; i++) {
+      index_node(c, c->m->kids[n->a + 2 * i], clause);
+      n = &c->m->nodes[node];
+    }
+    break;
   case CS_OP_NEG: case CS_OP_NOT:
     index_node(c, n->a, clause);
     break;
@@ -311,6 +328,53 @@ int cs_model_index(cs_model *m) {
   return 0;
 }
 
+/* One more top-level clause (a learnt conflict): a new root wide-and with `node` as its last element and, if the
+ * model carries a clause index, the clause appended to the lists of its variables -- where conflict_create
+ * puts it (conflict.c:352-358: clause_list_append for every element). */
+int cs_model_append_clause(cs_model *m, int32_t node) {
+  if (m->root < 0) return -1;
+  const int32_t cnt = m->nodes[m->root].b, off = m->nodes[m->root].a;
+  int32_t *elems = (int32_t *)xrealloc(NULL, (size_t)(cnt + 1) * sizeof(int32_t));
+  for (int32_t i = 0; i < cnt; i++) elems[i] = m->kids[off + i];
+  elems[cnt] = node;
+  m->root = cs_model_add_wand(m, elems, cnt + 1);
+  free(elems);
+  if (m->clause_node == NULL) return 0;
+  index_ctx c;
+  memset(&c, 0, sizeof c);
+  c.m = m;
+  c.lists = (ivec *)calloc((size_t)(m->n_vars ? m->n_vars : 1), sizeof(ivec));
+  const int32_t clause = m->n_clauses;
+  index_node(&c, node, clause);
+  m->clause_node = (int32_t *)xrealloc(m->clause_node, (size_t)(clause + 1) * sizeof(int32_t));
+  m->clause_node[clause] = node;
+  m->n_clauses = clause + 1;
+  if (m->clause_want != NULL) {
+    m->clause_want = (cs_val *)xrealloc(m->clause_want, (size_t)(clause + 1) * sizeof(cs_val));
+    m->clause_want[clause] = cs_interval(1, 1);
+  }
+  if (m->list_off != NULL) {
+    int32_t extra = 0;
+    for (int32_t v = 0; v < m->n_vars; v++) extra += c.lists[v].n;
+    const int32_t total = m->list_off[m->n_vars];
+    int32_t *list = (int32_t *)xrealloc(NULL, (size_t)(total + extra ? total + extra : 1) * sizeof(int32_t));
+    int32_t *loff = (int32_t *)xrealloc(NULL, (size_t)(m->n_vars + 1) * sizeof(int32_t));
+    int32_t w = 0;
+    for (int32_t v = 0; v < m->n_vars; v++) {
+      loff[v] = w;
+      for (int32_t i = m->list_off[v]; i < m->list_off[v + 1]; i++) list[w++] = m->list[i];
+      if (c.lists[v].n > 0) list[w++] = clause;
+    }
+    loff[m->n_vars] = w;
+    free(m->list); free(m->list_off);
+    m->list = list;
+    m->list_off = loff;
+  }
+  for (int32_t v = 0; v < m->n_vars; v++) free(c.lists[v].v);
+  free(c.lists);
+  return c.bad ? -1 : 0;
+}
+
 int32_t cs_model_first_unbounded(const cs_model *m) {
   for (int32_t v = 0; v < m->n_vars; v++)
     if (m->dom[v].lo == CS_DOM_MIN || m->dom[v].hi == CS_DOM_MAX) return v;
@@ -322,6 +386,7 @@ int32_t cs_model_tree_size(const cs_model *m, int32_t node) {
   switch (n->op) {
   case CS_OP_VAR: case CS_OP_CONST: return 1;
   case CS_OP_NEG: case CS_OP_NOT: return 1 + cs_model_tree_size(m, n->a);
+  case CS_OP_CONFL: return 1 + n->b;
   case CS_OP_WAND: {
     int32_t s = 1;
     for (int32_t i = 0; i < n->b; i++) s += cs_model_tree_size(m, m->kids[n->a + i]);
@@ -447,6 +512,12 @@ static int tree_equal(const cs_model *x, int32_t nx, const cs_model *y, int32_t 
     if (a->b != b->b) return 0;
     for (int32_t i = 0; i < a->b; i++)
       if (!tree_equal(x, x->kids[a->a + i], y, y->kids[b->a + i])) return 0;
+    return 1;
+  case CS_OP_CONFL:
+    if (a->b != b->b) return 0;
+    for (int32_t i = 0; i < a->b; i++)
+      if (x->kids[a->a + 2 * i + 1] != y->kids[b->a + 2 * i + 1] ||
+          !tree_equal(x, x->kids[a->a + 2 * i], y, y->kids[b->a + 2 * i])) return 0;
     return 1;
   default: return tree_equal(x, a->a, y, b->a) && tree_equal(x, a->b, y, b->b);
   }

@@ -73,6 +73,11 @@ int32_t cs_model_add_var(cs_model *m, const char *name, cs_val dom);
 int32_t cs_model_find_var(const cs_model *m, const char *name);
 int32_t cs_model_add_node(cs_model *m, int32_t op, int32_t a, int32_t b);
 int32_t cs_model_add_wand(cs_model *m, const int32_t *elems, int32_t n);
+/* a learnt conflict clause "not all of term_i == value_i" (struct confl_t, csolve.h:98-128): CS_OP_CONFL node,
+ * a = offset into kids[], b = number of elements; kids holds the pairs { terminal node, value } */
+/* append a top-level clause after the fact (root wide-and, and the clause index if the model has one) */
+int cs_model_append_clause(cs_model *m, int32_t node);
+int32_t cs_model_add_confl(cs_model *m, const int32_t *term_nodes, const int32_t *values, int32_t n);
 void cs_model_set_root_from_top(cs_model *m);
 
 /* text -> model; returns NULL and fills err on a parse error */

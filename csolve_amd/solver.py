@@ -122,6 +122,13 @@ class Model:
         check(load_library().csgpu_model_normalize(self._h))
         return self
 
+    def add_conflict(self, elems):
+        """a learnt conflict clause "not all of var == value" for elems = [(var, value)] (csgpu_model_add_conflict)"""
+        vs = np.ascontiguousarray([e[0] for e in elems], dtype=np.int32)
+        cs = np.ascontiguousarray([e[1] for e in elems], dtype=np.int32)
+        check(load_library().csgpu_model_add_conflict(self._h, len(elems), vs.ctypes.data, cs.ctypes.data))
+        return self
+
     def finalize(self):
         check(load_library().csgpu_model_finalize(self._h))
         self.finalized = True
@@ -253,6 +260,20 @@ class Model:
                                                  out.ctypes.data, C.byref(res)))
         return res.status, res.props, out
 
+
+    def propagate_one_traced(self, state: np.ndarray, var: int, lo: int, hi: int, cap: int = 4096):
+        """One node with its trail (csgpu_propagate_one_traced).
+        -> (status, props, fixpoint or None, trace [k, 4] = {variable, 0 lo / 1 hi / 2 failure, new bound, clause})"""
+        state = np.ascontiguousarray(state, dtype=np.int32)
+        out = np.empty_like(state)
+        res = Result()
+        trace = np.empty((cap, 4), dtype=np.int32)
+        cnt = C.c_int32()
+        check(load_library().csgpu_propagate_one_traced(self._h, state.ctypes.data, Node(var, lo, hi, 0), out.ctypes.data,
+                                                        C.byref(res), trace.ctypes.data, cap, C.byref(cnt)))
+        if cnt.value > cap:
+            raise OverflowError(f"{cnt.value} trace records, room for {cap}")
+        return res.status, res.props, (out if res.status >= 0 else None), trace[: cnt.value].copy()
 
     def propagate_values(self, state: np.ndarray, var: int, values):
         """Several values of `var` on one parent state, host buffers (the drop-in's sibling batch).

@@ -112,6 +112,13 @@ int csgpu_model_root_propagate_limit(csgpu_model *m, int64_t limit, int32_t *sta
  * src/normalize.c:305-316, parser.y:66): a host-side rewrite of the trees (constant folding,
  * neutral elements, constants moved across `<`, double negation, De Morgan); no domain changes. */
 int csgpu_model_normalize(csgpu_model *m);
+/* A learnt conflict clause (struct confl_t, csolve.h:98-128; conflict_create, conflict.c:319-361): "not all of
+ * vars[i] == values[i]".  It is evaluated like eval_confl (eval.c:258-277) and propagated like propagate_confl
+ * (propagate.c:395-471: when every element but one has its conflict value, that value is shaved off the bound of
+ * the remaining variable it sits on).  The clause becomes the last top-level clause and the last entry of its
+ * variables' clause lists.  May be called before or after csgpu_model_finalize; afterwards the device tables are
+ * rebuilt (the call costs O(model)).  At most 255 elements (CSGPU_E_LIMIT). */
+int csgpu_model_add_conflict(csgpu_model *m, int32_t count, const int32_t *vars, const int32_t *values);
 
 /* eval_<op> on the current root domains, host buffers, no finalize needed (variables may
  * still be unbounded): vals[c] = interval value of clause c (eval.c:27-255).  Synchronous. */
@@ -322,6 +329,16 @@ int csgpu_propagate_values(const csgpu_model *m, const csgpu_val *state, int32_t
  * uploads `state` (n_vars), runs one node, downloads the result.  Synchronous. */
 int csgpu_propagate_one(const csgpu_model *m, const csgpu_val *state, csgpu_node node, csgpu_val *state_out,
                         csgpu_result *result);
+/* The same with the node's trail: every narrowing the fixpoint made, as {variable, 0 = lower bound raised /
+ * 1 = upper bound lowered / 2 = failure seen at this variable (-1: at a constant), new bound, clause}, `clause`
+ * being the index of the top-level clause (csgpu_model_num_clauses order) whose revision made it -- what the
+ * reference's bind() records as binding_t.clause (csolve.h:73-79) for its conflict analysis (conflict.c:290-316).
+ * trace: host, [4 * cap] int32; *count = records made (may exceed cap: the rest is lost).  Records of one round
+ * are in no particular order; replaying them in sequence (intersecting) gives the fixpoint.  Runs the general
+ * kernel whatever csgpu_model_set_kernel says; the order of narrowings is the device's, not the reference's
+ * depth-first one, so a conflict derived from the trail is valid but not necessarily the reference's. */
+int csgpu_propagate_one_traced(const csgpu_model *m, const csgpu_val *state, csgpu_node node, csgpu_val *state_out,
+                               csgpu_result *result, int32_t *trace, int32_t cap, int32_t *count);
 
 #ifdef __cplusplus
 }

@@ -326,6 +326,14 @@ static cs_val ev(cso *o, int32_t node) {
     }
     return all_true ? iv(1, 1) : tv_unknown();
   }
+  case CS_OP_CONFL: /* eval.c:258-277: elements in order; the first one that is not a value decides "unknown", the
+                     * first value different from its conflict value decides "true" */
+    for (int32_t i = 0; i < n->b; i++) {
+      cs_val v = ev(o, o->m->kids[n->a + 2 * i]);
+      if (!v_is_value(v)) return tv_unknown();
+      if (v.lo != o->m->kids[n->a + 2 * i + 1]) return iv(1, 1);
+    }
+    return tv_unknown();
   default:
     return tv_unknown();
   }
@@ -527,6 +535,32 @@ static int32_t prop(cso *o, int32_t node, cs_val val, int32_t clause) {
       }
     }
     return sum;
+  }
+  case CS_OP_CONFL: { /* propagate.c:395-471 */
+    if (!v_is_true(val)) return 0;
+    /* propagate_confl_find (405-440): the single element that is not a value, provided every other element has
+     * its conflict value.  (The reference also moves the element(s) that stopped the scan to the front of the
+     * array; that shortens its next scan and changes no result of propagate_confl.  eval_confl of a reordered
+     * clause can answer [0,1] where the original order answers 1 -- a value only the in-search normalise tail
+     * consumes, which is out of scope here.) */
+    int32_t p = -1;
+    for (int32_t i = 0; i < n->b; i++) {
+      cs_val v = ev(o, o->m->kids[n->a + 2 * i]);
+      if (v_is_value(v)) {
+        if (v.lo != o->m->kids[n->a + 2 * i + 1]) return 0;
+      } else if (p < 0) {
+        p = i;
+      } else {
+        return 0;
+      }
+    }
+    if (p < 0) return 0;
+    /* propagate_confl_infer (443-457) */
+    const int32_t term = o->m->kids[n->a + 2 * p], cv = o->m->kids[n->a + 2 * p + 1];
+    cs_val v = ev(o, term);
+    if (v.lo == cv && v.lo != CS_DOM_MIN && v.lo != CS_DOM_MAX) return prop(o, term, iv(v.lo + 1, CS_DOM_MAX), clause);
+    if (v.hi == cv && v.hi != CS_DOM_MIN && v.hi != CS_DOM_MAX) return prop(o, term, iv(CS_DOM_MIN, v.hi - 1), clause);
+    return 0;
   }
   default:
     return 0;

@@ -38,10 +38,8 @@ class Result(C.Structure):
 
 def build(force: bool = False) -> str:
     """Compile liboracle.so with gcc (a few seconds)."""
-    stale = not os.path.exists(_LIB_PATH) or any(
-        os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH) for f in ("cs_oracle.c", "cs_oracle.h"))
-    if force or stale:
-        subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
+    # make knows the dependencies (the host sources under csolve_amd/csrc are part of the library)
+    subprocess.check_call(["make", "-s", "-C", _HERE] + (["-B"] if force else []) + ["liboracle.so"])
     return _LIB_PATH
 
 
@@ -76,6 +74,9 @@ def lib():
         L.cs_model_add_node.argtypes = [vp, i32, i32, i32]
         L.cs_model_add_wand.restype = i32
         L.cs_model_add_wand.argtypes = [vp, C.POINTER(i32), i32]
+        L.cs_model_add_confl.restype = i32
+        L.cs_model_add_confl.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), i32]
+        L.cs_model_append_clause.argtypes = [vp, i32]
         L.cs_model_equal.argtypes = [vp, vp, C.c_char_p, sz]
         L.cs_model_first_unbounded.restype = i32
         L.cs_model_first_unbounded.argtypes = [vp]
@@ -193,6 +194,18 @@ class Model:
     def add_wand(self, elems) -> int:
         arr = (C.c_int32 * max(1, len(elems)))(*elems)
         return lib().cs_model_add_wand(self.ptr, arr, len(elems))
+
+    def add_confl(self, elems) -> int:
+        """elems: [(terminal node, conflict value)] -- a learnt conflict clause"""
+        n = len(elems)
+        nodes = (C.c_int32 * max(1, n))(*[e[0] for e in elems])
+        vals = (C.c_int32 * max(1, n))(*[e[1] for e in elems])
+        return lib().cs_model_add_confl(self.ptr, nodes, vals, n)
+
+    def append_clause(self, node: int):
+        """one more top-level clause (and clause-index entry, if the model is indexed)"""
+        if lib().cs_model_append_clause(self.ptr, node) != 0:
+            raise ValueError("cs_model_append_clause failed")
 
     def set_root(self, node: int):
         self.view.root = node

@@ -131,8 +131,14 @@ def handle_decl(env: Env, s: str) -> bool:
     if m:
         env.exprs[m.group(1)] = ["WAND", env.arrays[m.group(3)][: int(m.group(2))]]
         return True
-    if "confl_elem_t" in s1 or "CONSTRAINT_CONFL" in s1:
-        env.skip = True  # conflict clauses are not restated
+    m = re.fullmatch(r"struct confl_elem_t (\w+) ?\[\d+\] = \{(.*)\}", s1)
+    if m:
+        env.arrays[m.group(1)] = [[t, val(v)[0]] for v, t in
+                                  re.findall(r"\.val = (VALUE\([^)]*\)), \.var = &(\w+)", m.group(2))]
+        return True
+    m = re.fullmatch(r"(?:struct constr_t )?(\w+) = CONSTRAINT_CONFL\((\d+), (\w+)\)", s1)
+    if m:
+        env.exprs[m.group(1)] = ["CONFL", env.arrays[m.group(3)][: int(m.group(2))]]
         return True
     return False
 

@@ -19,7 +19,7 @@
  * two values in the driver's order in one launch (csgpu_propagate_values), later ones twice as many; calls are
  * served from the batch as long as the other variables' domains are what they were (checked on every call).
  * Same search, call for call; off by default because it does not pay on the driver's depth-first descent.
- * Not reproduced: conflict-clause creation (run the driver with -c false), the in-search normalise/patch tail.
+ * Conflict learning (-c true): see learning() below.  Not reproduced: the in-search normalise/patch tail.
  */
 #include "../../include/csolve_dropin.h"
 
@@ -28,12 +28,15 @@
 #include <string.h>
 #include <time.h>
 
+#include "cs_device.h"
 #include "cs_internal.h"
 
 /* ---- provided by the reference driver ------------------------------------------------ */
 extern void bind(struct env_t *var, struct val_t val, const struct wand_expr_t *clause);
 extern void strategy_var_order_update(struct env_t *e);
 extern void conflict_reset(void);
+extern void conflict_create(struct env_t *var, const struct wand_expr_t *clause); /* conflict.c:319-361 */
+extern int strategy_create_conflicts(void);                                      /* strategy.c (bool) */
 extern void print_fatal(const char *fmt, ...);
 extern uint64_t props;
 
@@ -52,8 +55,9 @@ static int op_of(const struct constr_t *c) {
   case '&': return CS_OP_AND;
   case '|': return CS_OP_OR;
   case 'A': return CS_OP_WAND;
+  case 'C': return CS_OP_CONFL;
   default:
-    print_fatal("conflict clauses are not supported by the GPU propagator (run with -c false): %02x", c->type->op);
+    print_fatal("constraint type without a device implementation: %02x", c->type->op);
     return -1;
   }
 }
@@ -161,6 +165,17 @@ static int32_t flat_node(flat *f, struct constr_t *c, int in_root_path) {
     }
     id = cs_model_add_wand(f->m, kids, (int32_t)n);
     free(kids);
+  } else if (op == CS_OP_CONFL) { /* a learnt clause: terminals and the values they must not all have */
+    size_t n = c->constr.confl.length;
+    int32_t *terms = (int32_t *)malloc((n ? n : 1) * sizeof *terms);
+    int32_t *vals = (int32_t *)malloc((n ? n : 1) * sizeof *vals);
+    for (size_t i = 0; i < n; i++) {
+      terms[i] = flat_node(f, c->constr.confl.elems[i].var, 0);
+      vals[i] = c->constr.confl.elems[i].val.lo;
+    }
+    id = cs_model_add_confl(f->m, terms, vals, (int32_t)n);
+    free(terms);
+    free(vals);
   } else {
     int32_t l = flat_node(f, c->constr.expr.l, 0);
     int32_t r = c->constr.expr.r != NULL ? flat_node(f, c->constr.expr.r, 0) : -1;
@@ -196,6 +211,12 @@ static csgpu_model *g_model;      /* attached search model */
 static int g_trace = -1;           /* CSOLVE_DROPIN_TRACE=1: entry points on stderr */
 #define TRACE(...) do { if (g_trace < 0) g_trace = getenv("CSOLVE_DROPIN_TRACE") != NULL; if (g_trace) { fprintf(stderr, __VA_ARGS__); fflush(stderr); } } while (0)
 static csgpu_val *g_state, *g_out;
+static const struct wand_expr_t **g_clause_ptr; /* device clause id -> the driver's clause */
+static int32_t g_n_clause_ptr;
+static size_t g_attached_lists;                 /* entries of all clause lists at attach time: they only grow */
+static int32_t *g_trail;
+#define CS_TRAIL_CAP 16384
+static uint64_t g_conflicts_offered, g_reattached;
 static uint64_t g_calls[4];
 static uint64_t g_sib_launches, g_sib_served; /* sibling batches launched, calls served from one */
 
@@ -225,6 +246,7 @@ static struct {
 #define CS_SIBLING_MAX 4096
 
 void csolve_dropin_sibling_counters(uint64_t out[2]) { out[0] = g_sib_launches; out[1] = g_sib_served; }
+void csolve_dropin_learning_counters(uint64_t out[2]) { out[0] = g_conflicts_offered; out[1] = g_reattached; }
 
 /* where the shim's time goes: [0] attach (flatten + finalize + upload), [1] inside the device calls of
  * propagate_clauses, [2] the rest of propagate_clauses (state marshalling, bind() replay) */
@@ -293,10 +315,28 @@ static int attach(struct env_t *env, size_t size, struct constr_t *root, int at_
   int32_t top = flat_node(&f, root, 1);
   if (f.m->nodes[top].op != CS_OP_WAND) top = cs_model_add_wand(f.m, &top, 1);
   f.m->root = top;
+  /* learnt conflict clauses live in the variables' lists only (conflict.c:352-358): each becomes one more
+   * top-level clause, in the order the lists show them */
+  for (size_t i = 0; i < size; i++)
+    for (size_t j = 0; j < env[i].clauses.length; j++) {
+      struct wand_expr_t *w = env[i].clauses.elems[j];
+      if (pmap_get(&clause_ids, w) >= 0 || w->constr->type->op != 'C') continue;
+      if (w->constr->constr.confl.length + 1 > CS_MAX_TREE_NODES)
+        print_fatal("a conflict clause of %zu elements exceeds the device's tree size", w->constr->constr.confl.length);
+      if (cs_model_append_clause(f.m, flat_node(&f, w->constr, 0)) != 0) print_fatal("%s", f.m->err);
+      pmap_put(&clause_ids, w, f.n_clauses++);
+    }
   /* clause index from the trees, per-variable lists from the DRIVER's own lists */
   if (cs_model_index(f.m) != 0) print_fatal("%s", f.m->err);
+  if (f.m->n_clauses != f.n_clauses) print_fatal("attach: %d clauses indexed, %d met", f.m->n_clauses, f.n_clauses);
+  free(g_clause_ptr);
+  g_clause_ptr = (const struct wand_expr_t **)calloc((size_t)(f.n_clauses ? f.n_clauses : 1), sizeof *g_clause_ptr);
+  g_n_clause_ptr = f.n_clauses;
+  for (size_t k = 0; k < clause_ids.cap; k++)
+    if (clause_ids.key[k] != NULL) g_clause_ptr[clause_ids.val[k]] = (const struct wand_expr_t *)clause_ids.key[k];
   size_t total = 0;
   for (size_t i = 0; i < size; i++) total += env[i].clauses.length;
+  g_attached_lists = total;
   free(f.m->list);
   f.m->list = (int32_t *)malloc((total ? total : 1) * sizeof(int32_t));
   total = 0;
@@ -340,6 +380,8 @@ static void collect_env(struct constr_t *c, pmap *seen, struct env_t **lo, struc
     }
   } else if (op == CS_OP_WAND) {
     for (size_t i = 0; i < c->constr.wand.length; i++) collect_env(c->constr.wand.elems[i].constr, seen, lo, hi);
+  } else if (op == CS_OP_CONFL) {
+    for (size_t i = 0; i < c->constr.confl.length; i++) collect_env(c->constr.confl.elems[i].var, seen, lo, hi);
   } else {
     collect_env(c->constr.expr.l, seen, lo, hi);
     if (c->constr.expr.r != NULL) collect_env(c->constr.expr.r, seen, lo, hi);
@@ -397,10 +439,87 @@ static prop_result_t deliver(int32_t var, const csgpu_result *res, const csgpu_v
   return res->props;
 }
 
+/* Conflict learning (the driver's -c true, its default): a failing node needs the trail -- which clause made
+ * which narrowing -- because conflict_create (conflict.c:319-361) walks it.  The device records it
+ * (csgpu_propagate_one_traced); the shim replays the narrowings through bind() WITH their clauses, and at the
+ * point of failure does what propagate_term_confl does (propagate.c:33-41).  The narrowings come in the order of
+ * the device's rounds, not of the reference's depth-first recursion: every conflict derived from them is a
+ * valid consequence of the problem, but it need not be the one the reference learns, so CALLS / CONFL of a
+ * learning run differ from the pure reference's.  CSOLVE_DROPIN_LEARN=0 switches the trail off (failing nodes
+ * then create no conflicts, as before). */
+static int learning(void) {
+  static int on = -1;
+  if (on < 0) {
+    const char *e = getenv("CSOLVE_DROPIN_LEARN");
+    on = e == NULL || atoi(e) != 0;
+  }
+  return on && strategy_create_conflicts();
+}
+
+static prop_result_t deliver_traced(int32_t var, const csgpu_result *res, const csgpu_val *out, int32_t count) {
+  props += (uint64_t)res->props;
+  const int32_t have = count < CS_TRAIL_CAP ? count : CS_TRAIL_CAP;
+  int32_t fail_var = -1;
+  const struct wand_expr_t *fail_clause = NULL;
+  for (int32_t r = 0; r < have; r++) {
+    const int32_t v = g_trail[4 * r], kind = g_trail[4 * r + 1], bound = g_trail[4 * r + 2], c = g_trail[4 * r + 3];
+    const struct wand_expr_t *w = c >= 0 && c < g_n_clause_ptr ? g_clause_ptr[c] : NULL;
+    if (kind == 2) { /* the device saw the node fail here */
+      if (v >= 0 && (size_t)v < g_size) { fail_var = v; fail_clause = w; }
+      break;
+    }
+    if (v < 0 || (size_t)v >= g_size) continue;
+    struct val_t now = g_env[v].val->constr.term.val;
+    if (kind == 0 && bound > now.lo) now.lo = bound;
+    else if (kind == 1 && bound < now.hi) now.hi = bound;
+    else continue; /* superseded by a record replayed before it */
+    if (now.lo > now.hi) { /* propagate_term finds the intersection empty before it binds (propagate.c:64-70) */
+      fail_var = v;
+      fail_clause = w;
+      break;
+    }
+    bind(&g_env[v], now, w);
+  }
+  if (res->status < 0) {
+    if (fail_var < 0 && res->rounds >= 0 && (size_t)res->rounds < g_size) fail_var = res->rounds;
+    if (fail_var >= 0) { /* propagate_term_confl (propagate.c:33-41) */
+      g_env[fail_var].prio++;
+      strategy_var_order_update(&g_env[fail_var]);
+      if (fail_clause != NULL && count <= CS_TRAIL_CAP) {
+        g_conflicts_offered++;
+        conflict_create(&g_env[fail_var], fail_clause);
+      }
+    }
+    return PROP_ERROR;
+  }
+  /* whatever the trail did not cover (it overflowed): bound without a clause, like a decision */
+  for (size_t i = 0; i < g_size; i++) {
+    const struct val_t now = g_env[i].val->constr.term.val;
+    if (out[i].lo != now.lo || out[i].hi != now.hi) {
+      struct val_t v = { out[i].lo, out[i].hi };
+      if (count <= CS_TRAIL_CAP) print_fatal("propagate_clauses: the trail of variable %zu does not end in its fixpoint", i);
+      bind(&g_env[i], v, NULL);
+    }
+  }
+  (void)var;
+  return res->props;
+}
+
 static prop_result_t propagate_clauses_timed(const struct clause_list_t *clauses);
 prop_result_t propagate_clauses(const struct clause_list_t *clauses) {
   eval_cache_drop();
   conflict_reset();
+  if (g_model != NULL && learning()) {
+    /* clause lists only grow (clause_list_append, util.c:267-271): a longer total means new learnt clauses */
+    size_t total = 0;
+    for (size_t i = 0; i < g_size; i++) total += g_env[i].clauses.length;
+    if (total != g_attached_lists) {
+      struct env_t *env = g_env;
+      const size_t size = g_size;
+      g_reattached++;
+      attach(env, size, g_root, 0);
+    }
+  }
   if (g_model == NULL) lazy_attach(clauses);
   const double t0 = now_s(), dev0 = g_seconds[1];
   const prop_result_t r = propagate_clauses_timed(clauses);
@@ -422,7 +541,7 @@ static prop_result_t propagate_clauses_timed(const struct clause_list_t *clauses
    * value, so on its depth-first searches speculation costs more than it saves */
   if (batching < 0) batching = getenv("CSOLVE_DROPIN_SIBLINGS") != NULL && atoi(getenv("CSOLVE_DROPIN_SIBLINGS")) != 0;
   const int32_t k = g_state[var].lo;
-  if (batching && g_state[var].lo == g_state[var].hi) {
+  if (batching && !learning() && g_state[var].lo == g_state[var].hi) {
     /* the iteration this call belongs to: same variable, every OTHER domain what it was */
     int same = g_sib.valid && g_sib.var == var && k >= g_sib.lo && k <= g_sib.hi;
     for (size_t i = 0; i < g_size && same; i++)
@@ -487,6 +606,15 @@ static prop_result_t propagate_clauses_timed(const struct clause_list_t *clauses
   csgpu_result res;
   TRACE("[dropin] propagate_clauses var=%d [%d,%d]\n", node.var, node.lo, node.hi);
   const double td = now_s();
+  if (learning()) {
+    if (g_trail == NULL) g_trail = (int32_t *)malloc((size_t)CS_TRAIL_CAP * 4 * sizeof(int32_t));
+    int32_t count = 0;
+    if (csgpu_propagate_one_traced(g_model, g_state, node, g_out, &res, g_trail, CS_TRAIL_CAP, &count) != CSGPU_OK)
+      fatal_gpu("propagate_clauses");
+    g_seconds[1] += now_s() - td;
+    TRACE("[dropin]   -> status %d props %d, %d trail records\n", res.status, res.props, count);
+    return deliver_traced(var, &res, g_out, count);
+  }
   if (csgpu_propagate_one(g_model, g_state, node, g_out, &res) != CSGPU_OK) fatal_gpu("propagate_clauses");
   g_seconds[1] += now_s() - td;
   TRACE("[dropin]   -> status %d props %d rounds %d\n", res.status, res.props, res.rounds);
@@ -563,6 +691,8 @@ static void collect_nodes(const struct constr_t *c, pmap *seen, const struct con
   pmap_put(seen, c, 1);
   if (c->type->op == 'A') {
     for (size_t i = 0; i < c->constr.wand.length; i++) collect_nodes(c->constr.wand.elems[i].constr, seen, list, n, cap);
+  } else if (c->type->op == 'C') {
+    /* elements are terminals: nothing below to value */
   } else {
     collect_nodes(c->constr.expr.l, seen, list, n, cap);
     if (c->constr.expr.r != NULL) collect_nodes(c->constr.expr.r, seen, list, n, cap);
@@ -689,14 +819,7 @@ struct val_t eval_term(const struct constr_t *constr) { return constr->constr.te
 #define EVAL_VIA_GPU(NAME)                                                                         \
   struct val_t eval_##NAME(const struct constr_t *constr) { return eval_tree(constr); }
 EVAL_VIA_GPU(eq) EVAL_VIA_GPU(lt) EVAL_VIA_GPU(neg) EVAL_VIA_GPU(add) EVAL_VIA_GPU(mul)
-EVAL_VIA_GPU(not) EVAL_VIA_GPU(and) EVAL_VIA_GPU(or) EVAL_VIA_GPU(wand)
-
-struct val_t eval_confl(const struct constr_t *constr) {
-  (void)constr;
-  print_fatal("conflict clauses are not supported by the GPU propagator (run with -c false)");
-  struct val_t v = { 0, 1 };
-  return v;
-}
+EVAL_VIA_GPU(not) EVAL_VIA_GPU(and) EVAL_VIA_GPU(or) EVAL_VIA_GPU(wand) EVAL_VIA_GPU(confl)
 
 /* ---- single-operator propagate ------------------------------------------------------------------- */
 
@@ -715,8 +838,9 @@ prop_result_t propagate_wand(struct constr_t *constr, struct val_t val, const st
   return propagate_tree(constr, val, clause, 1, -1);
 }
 
+/* propagate.c:461-471: only "true" is pushed into a conflict clause */
 prop_result_t propagate_confl(struct constr_t *constr, struct val_t val, const struct wand_expr_t *clause) {
-  (void)constr; (void)val; (void)clause;
-  print_fatal("conflict clauses are not supported by the GPU propagator (run with -c false)");
-  return PROP_ERROR;
+  if (!(val.lo > 0 || val.hi < 0)) return 0;
+  g_calls[3]++;
+  return propagate_tree(constr, val, clause, 1, -1);
 }

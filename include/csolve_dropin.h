@@ -115,6 +115,9 @@ void csolve_dropin_detach(void);
 void csolve_dropin_counters(uint64_t out[4]);
 /* sibling batching of propagate_clauses: [0] batches launched, [1] calls served from a batch already there */
 void csolve_dropin_sibling_counters(uint64_t out[2]);
+/* conflict learning (driver run with -c true): [0] failing nodes handed to the driver's conflict_create with
+ * their trail, [1] re-attachments after the driver's clause lists had grown by learnt clauses */
+void csolve_dropin_learning_counters(uint64_t out[2]);
 /* seconds spent so far in [0] attach, [1] the device calls of propagate_clauses, [2] the rest of propagate_clauses */
 void csolve_dropin_seconds(double out[3]);
 

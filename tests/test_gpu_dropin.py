@@ -95,3 +95,44 @@ def test_sibling_batches_keep_the_deterministic_trace():
     assert used["served_from_batch"] > 0
     for k in ("calls", "cuts", "solutions"):
         assert got[k] == want[k]
+
+
+def _sat_text(n, m, seed):
+    """0/1 variables, three-literal clauses, one statement per clause (fuzz/inputs/sat.txt style)"""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    cl = []
+    for _ in range(m):
+        vs = rng.choice(n, size=3, replace=False)
+        cl.append("(" + "|".join(("!" if rng.integers(2) else "") + f"x{v + 1}" for v in vs) + ")")
+    return cl, "ANY;\n" + "".join(c + ";\n" for c in cl) + "".join(f"0<=x{v + 1};x{v + 1}<=1;\n" for v in range(n))
+
+
+REF = os.path.join(ROOT, "oracle", "_ref", "csolve_ref")
+
+
+@pytest.mark.skipif(not (os.path.exists(BIN) and os.path.exists(REF)), reason="oracle/_ref not built (needs the reference tree)")
+@pytest.mark.parametrize("n,m,seed", [(40, 170, 1), (60, 255, 2), (50, 170, 5), (70, 250, 6)])
+def test_reference_driver_with_conflict_learning_on_gpu_propagator(n, m, seed, tmp_path):
+    """The reference's driver with ALL its defaults (-c true: conflict clauses) on the GPU propagator, 0/1
+    problems: failing nodes hand their trail to the driver's conflict_create, learnt clauses reach the device
+    (eval_confl / propagate_confl), and the verdict -- satisfiable or not, a satisfying assignment -- is the pure
+    reference's.  Learning pays as it does in the reference: fewer calls than with -c false."""
+    clauses, text = _sat_text(n, m, seed)
+    path = tmp_path / "sat.txt"
+    path.write_text(text)
+    p = subprocess.run([REF, "solve", str(path)], capture_output=True, text=True, timeout=300)
+    want = json.loads(re.search(r"@STATS (\{.*\})", p.stdout).group(1))
+    stats, used, sol = _run(str(path), [])
+    assert stats["solutions"] == want["solutions"], (stats, want)
+    if want["solutions"]:
+        for c in clauses:  # every clause has a true literal
+            lits = c.strip("()").split("|")
+            assert any((sol[l[1:]] == 0) if l.startswith("!") else (sol[l] == 1) for l in lits), c
+    assert stats["confl"] > 0 and used["conflicts_offered"] >= stats["confl"] and used["reattached"] > 0
+    off, _, _ = _run(str(path), ["-c", "false"])
+    assert off["solutions"] == want["solutions"] and off["confl"] == 0
+    if not want["solutions"]:
+        assert stats["calls"] <= off["calls"], (stats["calls"], off["calls"])
+    print(f"n={n} m={m}: reference calls {want['calls']} confl {want['confl']}; "
+          f"drop-in calls {stats['calls']} confl {stats['confl']}; drop-in -c false calls {off['calls']}")

@@ -60,6 +60,36 @@ __device__ __forceinline__ unsigned long long cs_bitset0(unsigned long long m, i
   return m;
 }
 
+/* x + (x == f) and x - (x == f): a compare into VCC and an add / subtract with carry-in */
+__device__ __forceinline__ int cs_inc_if_eq(int x, int f) {
+  int r;
+  asm("v_cmp_eq_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, 0, %1, vcc" : "=v"(r) : "v"(x), "v"(f) : "vcc");
+  return r;
+}
+__device__ __forceinline__ int cs_dec_if_eq(int x, int f) {
+  int r;
+  asm("v_cmp_eq_u32 vcc, %1, %2\n\tv_subb_co_u32 %0, vcc, %1, 0, vcc" : "=v"(r) : "v"(x), "v"(f) : "vcc");
+  return r;
+}
+
+/* v with lane L replaced by the wave-uniform x */
+template <int L>
+__device__ __forceinline__ int cs_writelane(int v, int x) {
+  x = __builtin_amdgcn_readfirstlane(x); /* free when the compiler already knows x to be uniform */
+  asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(x), "n"(L));
+  return v;
+}
+
+/* the lane is a constant after unrolling: the branches fold */
+__device__ __forceinline__ int cs_writelane_at(int lane, int v, int x) {
+  switch (lane) {
+  case 0: return cs_writelane<0>(v, x);
+  case 1: return cs_writelane<1>(v, x);
+  case 2: return cs_writelane<2>(v, x);
+  default: return cs_writelane<3>(v, x);
+  }
+}
+
 #define CS_SHAVE_CHUNK 2        /* nodes per chunk = parent rows in flight per wave */
 #define CS_SHAVE_SHARDS 64      /* ticket counters per launch at most */
 #define CS_SHAVE_TICKET_STRIDE 16 /* unsigned words between two counters: one 64-byte line each */
@@ -77,10 +107,14 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_shave(
   constexpr int W = CS_WAVE * R; /* columns of the table */
   constexpr int D = CS_SHAVE_CHUNK;
   if (batch_dev != nullptr && (long long)*batch_dev < batch) batch = (long long)*batch_dev;
+  /* the ABI's batches stay below 2^31 nodes: node numbers are 32-bit scalars from here on (the scalar unit, which
+   * bounds this kernel -- 119 scalar against 105 vector instructions per node on queens-64,
+   * profiles/r02_f_sq_counters_shave_queens64.txt -- multiplies 64-bit numbers in six instructions) */
+  const int nbatch = __builtin_amdgcn_readfirstlane((int)batch);
   const int lane = threadIdx.x & (CS_WAVE - 1);
   const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int waves_per_block = blockDim.x >> 6;
-  const int chunks = (int)((batch + csz - 1) / csz); /* the ABI's batches stay below 2^31 nodes */
+  const int chunks = (nbatch + csz - 1) / csz;
   /* shards: chunk c belongs to shard c mod nsh, local index c / nsh; workgroup b works on shard b mod nsh */
   const int nsh = (int)gridDim.x < CS_SHAVE_SHARDS ? (int)gridDim.x : CS_SHAVE_SHARDS;
   const int shard = (int)(blockIdx.x % nsh);
@@ -124,8 +158,8 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_shave(
   auto load_rec = [&](int i) {
     cs_node_in rec;
     rec.var = -1; rec.lo = 0; rec.hi = 0; rec.parent = 0;
-    const long long node = ((long long)i * nsh + shard) * csz + lane;
-    if (lane < csz && node < batch) rec = nodes[node];
+    const int node = (i * nsh + shard) * csz + lane;
+    if (lane < csz && node < nbatch) rec = nodes[node];
     return rec;
   };
   /* ticket -> local chunk index (a scalar); the wave that draws the shard's last ticket resets the counter */
@@ -160,7 +194,7 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_shave(
     /* the indices are wave-uniform by construction; say so (the compiler otherwise carries them in vector registers) */
     i_cur = __builtin_amdgcn_readfirstlane(i_cur);
     i_next = __builtin_amdgcn_readfirstlane(i_next);
-    have_next = __builtin_amdgcn_readfirstlane(have_next);
+    have_next = i_next < count_x; /* from the scalar: a flag carried through a vector register costs four instructions */
     if (have_next && dynamic) tk = draw(); /* for the chunk after the next one */
     cs_val pn[D][R]; /* parent rows of the next chunk (its records arrived during the previous step) */
 #pragma unroll
@@ -175,8 +209,8 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_shave(
         for (int r = 0; r < R; r++) pn[d][r] = states_in[prow + vcl[r]];
       }
     }
-    const long long base = ((long long)i_cur * nsh + shard) * csz;
-    const int cnt = (int)(batch - base < csz ? batch - base : csz);
+    const int base = (i_cur * nsh + shard) * csz;
+    const int cnt = nbatch - base < csz ? nbatch - base : csz;
 #ifdef CS_SHAVE_TIMELINE
     tl_nodes += cnt;
 #endif
@@ -229,17 +263,21 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_shave(
       auto push_var = [&](int r, int ul, int cd) {
         revisions += __builtin_amdgcn_readlane(deg[r], ul);
         const E *row = s_tab + (size_t)(ul + r * CS_WAVE) * slots * W + lane;
-        u64 ml[R], mh[R]; /* lanes whose lower / upper bound is the forbidden value */
+        /* The slots are applied one after the other to the bounds as they stand (a bound moved by slot k may be moved
+         * again by slot k + 1: both values are forbidden by u, each move is one narrowing); `bound += (f == bound)` is
+         * a compare into VCC and an add with carry-in, and which bounds moved is ONE compare per bound at the end --
+         * the scalar unit merges nothing. */
+        int plo[R], phi[R];
 #pragma unroll
-        for (int r2 = 0; r2 < R; r2++) { ml[r2] = 0ull; mh[r2] = 0ull; }
+        for (int r2 = 0; r2 < R; r2++) { plo[r2] = rlo[r2]; phi[r2] = rhi[r2]; }
         if (SL != 0) {
 #pragma unroll
           for (int k = 0; k < (SL ? SL : 1); k++) {
 #pragma unroll
             for (int r2 = 0; r2 < R; r2++) {
               const int f = cd - (int)row[k * W + r2 * CS_WAVE]; /* the value of w that u forbids (sentinel: < 0) */
-              ml[r2] |= __ballot(f == rlo[r2]);
-              mh[r2] |= __ballot(f == rhi[r2]);
+              rlo[r2] = cs_inc_if_eq(rlo[r2], f);
+              rhi[r2] = cs_dec_if_eq(rhi[r2], f);
             }
           }
         } else {
@@ -247,17 +285,15 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_shave(
 #pragma unroll
             for (int r2 = 0; r2 < R; r2++) {
               const int f = cd - (int)row[k * W + r2 * CS_WAVE];
-              ml[r2] |= __ballot(f == rlo[r2]);
-              mh[r2] |= __ballot(f == rhi[r2]);
+              rlo[r2] = cs_inc_if_eq(rlo[r2], f);
+              rhi[r2] = cs_dec_if_eq(rhi[r2], f);
             }
           }
         }
 #pragma unroll
         for (int r2 = 0; r2 < R; r2++) {
-          rlo[r2] += __builtin_amdgcn_inverse_ballot_w64(ml[r2]) ? 1 : 0;
-          rhi[r2] -= __builtin_amdgcn_inverse_ballot_w64(mh[r2]) ? 1 : 0;
-          dl[r2] |= ml[r2];
-          dh[r2] |= mh[r2];
+          dl[r2] |= __ballot(rlo[r2] != plo[r2]);
+          dh[r2] |= __ballot(rhi[r2] != phi[r2]);
         }
       };
       /* the fixpoint; returns -1, or a variable whose domain has become empty (what the reference's
@@ -423,7 +459,7 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_shave(
         shaved += (rlo[r] - lo0[r]) + (hi0[r] - rhi[r]);
       }
       const int props = cs_wave_sum(shaved);
-      const size_t orow = (size_t)(base + j) * n;
+      const size_t orow = (size_t)(unsigned)(base + j) * (unsigned)n;
       if (FULL) {
 #pragma unroll
         for (int r = 0; r < R; r++) states_out[orow + lane + r * CS_WAVE] = cs_interval(rlo[r] + b0[r], rhi[r] + b0[r]);
@@ -432,12 +468,11 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_shave(
         for (int r = 0; r < R; r++)
           if (live[r]) states_out[orow + lane + r * CS_WAVE] = cs_interval(rlo[r] + b0[r], rhi[r] + b0[r]);
       }
-      if (lane == j) {
-        my_result.status = failed ? -1 : open_vars;
-        my_result.props = props;
-        my_result.revisions = revisions;
-        my_result.rounds = failed ? fail_var : rounds; /* an inconsistent node reports the failing variable here */
-      }
+      /* lane j of the four result registers, one v_writelane each (the lane number is a constant of the unrolled copy) */
+      my_result.status = cs_writelane_at(dd, my_result.status, failed ? -1 : open_vars);
+      my_result.props = cs_writelane_at(dd, my_result.props, props);
+      my_result.revisions = cs_writelane_at(dd, my_result.revisions, revisions);
+      my_result.rounds = cs_writelane_at(dd, my_result.rounds, failed ? fail_var : rounds); /* an inconsistent node reports the failing variable here */
     }
     if (lane < cnt) results[base + lane] = my_result;
 

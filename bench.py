@@ -351,6 +351,7 @@ def main():
                          "interval states in and out, nothing precomputed); intervals+sets = csgpu_propagate_batch_fb "
                          "with resident forbidden sets; sets = csgpu_propagate_batch_sets (bit-vector states)")
     ap.add_argument("--no-queens128", action="store_true", help="skip the queens-128 sub-record of the default run")
+    ap.add_argument("--no-sudoku25", action="store_true", help="skip the sudoku-25 sub-record (BASELINE configs[2]) of the default run")
     ap.add_argument("--workload", choices=["propagate", "search"], default="propagate")
     ap.add_argument("--process-group", action="store_true", help="create the process group even for one rank (the "
                     "collectives of the search workload then run over RCCL / gloo with world size 1)")
@@ -465,6 +466,8 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args, text, model, legs["states_in"], legs["nodes"], head["states_out"], res_h)
         if not (args.sudoku or args.schedule) and n_q == 64 and not args.no_queens128:
             out["queens128"] = queens128_record(args)
+            if not args.no_sudoku25:
+                out["sudoku25"] = sudoku25_record(args)
             e2e = end_to_end_record()
             if e2e is not None:
                 out["end_to_end"] = e2e
@@ -681,6 +684,28 @@ def queens128_record(args):
     ok = leg["results"][:, 0] >= 0
     t = leg["kernel_ms"] * 1e-3
     out = {"workload": "queens-128 propagation-only fixpoint, 131072 seeded random-walk node instances resident in HBM",
+           "entry": leg["entry"], "forbidden_sets_precomputed": False, "steps": leg["steps"],
+           "nodes_per_s": legs["B"] / t, "value": int(leg["results"][ok, 1].sum()) / t, "unit": "propagations/s",
+           "roofline": rec}
+    out["cpu_baseline"] = cpu_baseline(a, text, legs["model"], legs["states_in"], legs["nodes"], leg["states_out"], leg["results"])
+    out["speedup_over_reference_core"] = out["value"] / out["cpu_baseline"]["value"]
+    return out
+
+
+def sudoku25_record(args):
+    """BASELINE configs[2] next to the headline: the 25x25 sudoku-shaped != network (625 variables, 72 neighbours each),
+    2^18 seeded node instances, state-only entry, a sample re-checked against the compiled reference."""
+    import copy
+    a = copy.copy(args)
+    a.queens, a.sudoku, a.schedule, a.layout = 64, 5, 0, "intervals"
+    a.cpu_seconds = min(args.cpu_seconds, 4.0)
+    text = problems.sudoku(5, 0.3, 1)
+    legs = run_propagation_legs(a, text, 1 << 18, seed=555, headline_only=True, steps=min(args.steps, 30))
+    leg = legs["legs"]["state_only"]
+    rec = roofline_record(leg, "sudoku-25x25", legs["B"])
+    ok = leg["results"][:, 0] >= 0
+    t = leg["kernel_ms"] * 1e-3
+    out = {"workload": "sudoku-25x25 (30 % givens) propagation-only fixpoint, 262144 seeded random-walk node instances resident in HBM",
            "entry": leg["entry"], "forbidden_sets_precomputed": False, "steps": leg["steps"],
            "nodes_per_s": legs["B"] / t, "value": int(leg["results"][ok, 1].sum()) / t, "unit": "propagations/s",
            "roofline": rec}

@@ -58,6 +58,7 @@ struct csgpu_model {
   void *d_adj_packed;
   int lds_waves;     /* waves per workgroup of the LDS-resident kernel, 0 = not eligible */
   size_t lds_bytes;  /* its dynamic LDS size */
+  int lds_adj_global; /* kernel 2 reads its adjacency through L2 (the lists would leave LDS for fewer than 16 waves) */
   size_t k1_tab_bytes; /* general kernel: adj_off + adj + lit copied into LDS by every workgroup (0: read through L2) */
   int fb_words;      /* forbidden-set words per variable (0 = not eligible) */
   int fb_waves;
@@ -460,10 +461,10 @@ extern "C" int csgpu_model_eval_clauses_host(csgpu_model *m, csgpu_val *vals) {
 
 /* instantiation of the LDS-resident kernel for an entry width and a prefetch depth
  * R = ceil(n_vars / 64) rounded up to a power of two (at most 16: larger states load their tail in place) */
-static const void *ne_lds_kernel(int width, int n_vars) {
+static const void *ne_lds_kernel(int width, int n_vars, int adj_global) {
   int r = 1;
   while (r < 16 && r * CS_WAVE < n_vars) r <<= 1;
-#define CS_PICK_U(E, RR) return (const void *)cs_propagate_ne_lds<E, RR, 1>;
+#define CS_PICK_U(E, RR) return adj_global ? (const void *)cs_propagate_ne_lds<E, RR, 1, false> : (const void *)cs_propagate_ne_lds<E, RR, 1, true>;
 #define CS_PICK(E)                                                                                 \
   switch (r) {                                                                                     \
   case 1: CS_PICK_U(E, 1)                                                                          \
@@ -683,6 +684,7 @@ extern "C" int csgpu_model_finalize(csgpu_model *m) {
     const size_t off_bytes = (((size_t)h->n_vars * 2 * sizeof(int)) + 15) & ~(size_t)15;
     const size_t adj_bytes = (((size_t)m->img->n_adj * (size_t)m->img->packed_width) + 15) & ~(size_t)15;
     const size_t lds_slice = ((size_t)h->n_vars * sizeof(cs_val) + (2 * (size_t)m->tab.n_words + 1) * sizeof(unsigned) + 15) & ~(size_t)15;
+    m->lds_adj_global = 0;
     for (int waves = 16; waves >= 4; waves >>= 1) {
       const size_t need = off_bytes + adj_bytes + (size_t)waves * lds_slice;
       if (need <= 160u * 1024u) {
@@ -691,11 +693,18 @@ extern "C" int csgpu_model_finalize(csgpu_model *m) {
         break;
       }
     }
+    if (m->lds_waves < 16 && 8 * lds_slice <= 160u * 1024u) {
+      /* the lists leave LDS for a few waves only: keep them in device memory (L2-resident, every workgroup reads the
+       * same few tens of KB) and give LDS to the node slices -- workgroups of 8 waves, as many per CU as fit */
+      m->lds_adj_global = 1;
+      m->lds_waves = 8;
+      m->lds_bytes = 8 * lds_slice;
+    }
     if (m->lds_waves) {
       if ((rc = upload(m->img->adj_packed, (size_t)m->img->n_adj * (size_t)m->img->packed_width,
                        (int **)&m->d_adj_packed)))
         return rc;
-      if ((rc = lds_limit(m->lds_bytes, ne_lds_kernel(m->img->packed_width, h->n_vars)))) return rc;
+      if ((rc = lds_limit(m->lds_bytes, ne_lds_kernel(m->img->packed_width, h->n_vars, m->lds_adj_global)))) return rc;
     }
   }
 
@@ -1076,7 +1085,11 @@ extern "C" int csgpu_model_get_kernel(const csgpu_model *m) {
     /* no sets passed: small models several nodes per wave with the sets rebuilt (5), otherwise the
      * interval-only shaving kernel (7), which needs no sets at all */
     if (m->dense_waves) return packed_nodes_per_wave(m->fb_words, m->host->n_vars, m->img->dense_width) ? 5 : 7;
-    return 3;
+    /* more than 256 variables and no sets to inherit: rebuilding them costs one list scan per VALUED variable of
+     * the incoming state (sudoku-25, 2^18 nodes: 6.2 ms), the event-driven kernels scan one list per narrowing
+     * (kernel 2: 1.16 ms, kernel 1: 1.18 ms).  Callers that carry the sets use csgpu_propagate_batch_fb (kernel 3:
+     * 0.91 ms on that batch). */
+    return m->lds_waves ? 2 : 1;
   }
   if (m->lds_waves) return 2;
   const int cpl = clause_rounds_cpl(m);
@@ -1151,16 +1164,20 @@ extern "C" int csgpu_internal_propagate_objdev(const csgpu_model *m, const csgpu
     if (wg_per_cu > (size_t)(32 / m->lds_waves)) wg_per_cu = (size_t)(32 / m->lds_waves);
     if (wg_per_cu < 1) wg_per_cu = 1;
     int64_t grid = (int64_t)m->n_cus * (int64_t)wg_per_cu;
-    const int64_t chunks = (batch + CS_CHUNK - 1) / CS_CHUNK;
+    /* nodes a wave takes at a time: 16 when every wave gets several such chunks, fewer for smaller batches (a wave
+     * with two chunks next to one with one is a launch twice as long as it needs to be) */
+    int csz = (int)(batch / (grid * m->lds_waves * 4));
+    csz = csz < 1 ? 1 : (csz > CS_CHUNK ? CS_CHUNK : csz);
+    const int64_t chunks = (batch + csz - 1) / csz;
     const int64_t need = (chunks + m->lds_waves - 1) / m->lds_waves;
     if (grid > need) grid = need;
     const dim3 blk((unsigned)(m->lds_waves * CS_WAVE));
     int n_adj = m->img->n_adj, obits = m->img->packed_obits, dmin = m->img->packed_dmin;
     long long nb = (long long)batch;
     const void *packed = m->d_adj_packed;
-    void *args[] = { &tab, &packed, &n_adj, &obits, &dmin, &in, &nodes, &out, &res, &nb };
-    HIP_TRY(hipLaunchKernel(ne_lds_kernel(m->img->packed_width, m->host->n_vars), dim3((unsigned)grid), blk, args,
-                            m->lds_bytes, s));
+    void *args[] = { &tab, &packed, &n_adj, &obits, &dmin, &in, &nodes, &out, &res, &nb, &csz };
+    HIP_TRY(hipLaunchKernel(ne_lds_kernel(m->img->packed_width, m->host->n_vars, m->lds_adj_global), dim3((unsigned)grid),
+                            blk, args, m->lds_bytes, s));
     return CSGPU_OK;
   }
   /* kernel 6 when asked for; automatically for models of at most 256 clauses (faster at every batch size

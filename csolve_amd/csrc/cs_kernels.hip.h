@@ -756,13 +756,17 @@ __global__ __launch_bounds__(CS_BLOCK) void cs_propagate_clause_rounds(cs_tables
  */
 #define CS_CHUNK 16 /* nodes a wave takes at a time: their records sit in lanes 0..15 */
 
-template <typename E, int R, int U>
+/* ADJ_LDS = false: the adjacency stays in device memory (it is a few tens of KB that every workgroup reads: L2-resident)
+ * and LDS holds the per-wave slices only -- for models whose lists would leave room for a handful of waves (a 25x25
+ * sudoku: 90 KB of lists, 5 KB per node), where latency, not LDS bandwidth, is what needs hiding.
+ * csz: nodes a wave takes at a time (1..16; small for small batches, so that every wave gets a share). */
+template <typename E, int R, int U, bool ADJ_LDS = true>
 __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_lds(cs_tables T, const E *__restrict__ adj_packed, int n_adj,
                                                             int obits, int dmin,
                                                             const cs_val *__restrict__ states_in,
                                                             const cs_node_in *__restrict__ nodes,
                                                             cs_val *__restrict__ states_out,
-                                                            cs_node_out *__restrict__ results, long long batch) {
+                                                            cs_node_out *__restrict__ results, long long batch, int csz) {
   extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
   const int lane = threadIdx.x & (CS_WAVE - 1);
   const int wave_in_block = threadIdx.x >> 6;
@@ -771,9 +775,9 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_lds(cs
   /* LDS: {begin,end} of every list [n] | packed adjacency | one slice per wave
    * (domains, two masks, the propagation counter) */
   int2 *s_off2 = (int2 *)cs_lds;
-  const size_t off_bytes = (((size_t)n * sizeof(int2)) + 15) & ~(size_t)15;
+  const size_t off_bytes = ADJ_LDS ? (((size_t)n * sizeof(int2)) + 15) & ~(size_t)15 : 0;
   E *s_adj = (E *)(cs_lds + off_bytes);
-  const size_t adj_bytes = (((size_t)n_adj * sizeof(E)) + 15) & ~(size_t)15;
+  const size_t adj_bytes = ADJ_LDS ? (((size_t)n_adj * sizeof(E)) + 15) & ~(size_t)15 : 0;
   const size_t slice = (size_t)n * sizeof(cs_val) + (2 * (size_t)nw + 1) * sizeof(unsigned);
   const size_t slice_al = (slice + 15) & ~(size_t)15;
   cs_val *dom = (cs_val *)(cs_lds + off_bytes + adj_bytes + wave_in_block * slice_al);
@@ -781,16 +785,18 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_lds(cs
   unsigned *mask_b = mask_a + nw;
   unsigned *pcount = mask_b + nw;
 
-  for (int i = threadIdx.x; i < n; i += blockDim.x) s_off2[i] = make_int2(T.adj_off[i], T.adj_off[i + 1]);
-  for (int i = threadIdx.x; i < n_adj; i += blockDim.x) s_adj[i] = adj_packed[i];
-  __syncthreads();
+  if (ADJ_LDS) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s_off2[i] = make_int2(T.adj_off[i], T.adj_off[i + 1]);
+    for (int i = threadIdx.x; i < n_adj; i += blockDim.x) s_adj[i] = adj_packed[i];
+    __syncthreads();
+  }
 
   const unsigned omask = (1u << obits) - 1u;
-  const long long chunks = (batch + CS_CHUNK - 1) / CS_CHUNK;
+  const long long chunks = (batch + csz - 1) / csz;
   const long long waves_total = (long long)gridDim.x * waves_per_block;
   for (long long chunk = (long long)blockIdx.x * waves_per_block + wave_in_block; chunk < chunks; chunk += waves_total) {
-    const long long base = chunk * CS_CHUNK;
-    const int cnt = (int)(batch - base < CS_CHUNK ? batch - base : CS_CHUNK);
+    const long long base = chunk * csz;
+    const int cnt = (int)(batch - base < csz ? batch - base : csz);
     /* the chunk's node records: one coalesced 16-byte load per lane, then register reads only */
     cs_node_in rec;
     rec.var = -1; rec.lo = 0; rec.hi = 0; rec.parent = 0;
@@ -866,14 +872,30 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_lds(cs
   } while (0)
       for (;;) {
         int any = 0;
+        /* the round's changed mask: lane w holds word w (one LDS read for up to 2048 variables), the words that are
+         * not empty are walked through a ballot */
+        unsigned my_word = 0u;
+        unsigned long long nonempty = 0ull;
+        if (nw <= CS_WAVE) {
+          my_word = lane < nw ? cur[lane] : 0u;
+          nonempty = __ballot(my_word != 0u);
+        }
         for (int w = 0; w < nw && !failed; w++) {
-          unsigned bits = __builtin_amdgcn_readfirstlane(cur[w]);
+          unsigned bits;
+          if (nw <= CS_WAVE) {
+            if (nonempty == 0ull) break;
+            w = __builtin_ctzll(nonempty);
+            nonempty &= nonempty - 1ull;
+            bits = __builtin_amdgcn_readlane(my_word, w);
+          } else {
+            bits = __builtin_amdgcn_readfirstlane(cur[w]);
+          }
           any |= bits != 0u;
           while (bits != 0u) {
             const int u = w * 32 + __builtin_ctz(bits);
             bits &= bits - 1u;
             const cs_val du = dom[u];
-            const int2 range = s_off2[u]; /* {begin, end} in one LDS read */
+            const int2 range = ADJ_LDS ? s_off2[u] : make_int2(T.adj_off[u], T.adj_off[u + 1]);
             const int ulo = __builtin_amdgcn_readfirstlane(du.lo), uhi = __builtin_amdgcn_readfirstlane(du.hi);
             if (ulo > uhi) { failed = 1; break; } /* bounds crossed by racing updates */
             const int beg = __builtin_amdgcn_readfirstlane(range.x), end = __builtin_amdgcn_readfirstlane(range.y);
@@ -886,7 +908,7 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_lds(cs
 #pragma unroll
               for (int k = 0; k < U; k++) {
                 const int i = i0 + k * CS_WAVE;
-                e[k] = i < end ? (unsigned)s_adj[i] : 0xffffffffu;
+                e[k] = i < end ? (unsigned)(ADJ_LDS ? s_adj[i] : adj_packed[i]) : 0xffffffffu;
               }
 #pragma unroll
               for (int k = 0; k < U; k++) dw[k] = e[k] != 0xffffffffu ? dom[e[k] & omask] : cs_interval(1, 0);

@@ -161,8 +161,10 @@ int csgpu_propagate_batch_sets(const csgpu_model *m, const uint64_t *d_sets_in, 
  * case through each of them.
  * Automatic: csgpu_propagate_batch_fb (sets passed) uses 5 when the model qualifies, else 4, else 3;
  * csgpu_propagate_batch (states only) uses 5 with the sets rebuilt for models of at most 32 variables,
- * else 7, else 3 with the sets rebuilt, else 2, else 6 (at most 256 clauses; with 257-512 for batches of
- * at most 8192 nodes only, where its lower latency counts and its lower throughput does not), else 1. */
+ * else 7, else 2 (more than 256 variables: rebuilding forbidden sets costs a list scan per valued variable of
+ * every incoming state, the event-driven kernels scan one list per narrowing), else 6 (at most 256 clauses;
+ * with 257-512 for batches of at most 8192 nodes only, where its lower latency counts and its lower throughput
+ * does not), else 1. */
 int csgpu_model_set_kernel(csgpu_model *m, int which);
 /* Process-wide switch for models finalized afterwards: 1 (default) = EQ / LT / two-literal OR clauses
  * over `VAR` or `VAR + constant` operands are revised by direct bound propagation (schedule.txt-style

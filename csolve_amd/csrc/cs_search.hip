@@ -98,6 +98,7 @@ struct csgpu_search {
   int64_t burst_limit; /* parents per iteration the graph was built for (0: none) */
   cs_holes holes;      /* values a parent's own set forbids are cut without a launch (one set word per variable) */
   int burst_off;       /* CSGPU_SEARCH_BURST=0: every iteration driven from the host */
+  int eval_always;     /* CSGPU_SEARCH_EVAL=1: complete children of pure != networks are evaluated all the same (tests) */
   int graph_off;       /* CSGPU_SEARCH_GRAPH=0: the launches of a burst enqueued one by one */
 };
 
@@ -845,14 +846,14 @@ __global__ __launch_bounds__(SB) void cs_accept(const cs_val *__restrict__ compl
     if (i != 0) return;
     int first = -1;
     for (int k = 0; k < count && first < 0; k++)
-      if (truth[k] == 1) first = k;
+      if (truth == nullptr || truth[k] == 1) first = k;
     if (first < 0 || counters[C_STORED] != 0ull) return;
     counters[C_SOLUTIONS] += 1ull;
     counters[C_STORED] = 1ull;
     for (int v = 0; v < n; v++) solutions[v] = complete[(size_t)(list != nullptr ? list[first] : first) * n + v].lo;
     return;
   }
-  const bool ok = i < count && truth[i] == 1;
+  const bool ok = i < count && (truth == nullptr || truth[i] == 1); /* truth == NULL: every complete child is a solution */
   const size_t row = ok ? (size_t)(list != nullptr ? list[i] : i) * n : 0;
   const unsigned long long mask = __ballot(ok);
   if (mask == 0ull) return;
@@ -1038,6 +1039,8 @@ extern "C" int csgpu_search_create(const csgpu_model *m, int64_t pool_capacity, 
   {
     const char *e = getenv("CSGPU_SEARCH_BURST");
     s->burst_off = e != NULL && e[0] == '0';
+    const char *ev = getenv("CSGPU_SEARCH_EVAL");
+    s->eval_always = ev != NULL && ev[0] == '1';
     e = getenv("CSGPU_SEARCH_GRAPH");
     s->graph_off = e != NULL && e[0] == '0';
   }
@@ -1403,12 +1406,19 @@ static int one_iteration(csgpu_search *s) {
   const int64_t complete = (int64_t)c[C_COMPLETE];
   if (complete > 0) {
     if (s->objective == CS_OBJ_ALL) {
-      /* evaluated and accepted where they lie, through the list of their child indices */
-      rc = csgpu_internal_eval_list(s->m, (const csgpu_val *)s->d_child_states, s->d_complete_list,
-                                    (const uint64_t *)(s->d_counters + C_COMPLETE), complete, s->d_truth, NULL);
-      if (rc != CSGPU_OK) return rc;
+      /* evaluated and accepted where they lie, through the list of their child indices.  On a pure != network
+       * (the models with forbidden sets, fw > 0) a complete consistent node IS a solution: a clause between two
+       * valued variables was revised when the second of them became a value and would have emptied a domain
+       * (propagate_eq_false_lr, propagate.c:106-120), and the root's own valued pairs were checked by the root
+       * phase -- evaluating the root (eval_wand over every clause, eval.c:233-255) can only say "true" */
+      const int *truth = s->fw > 0 && !s->eval_always ? (const int *)NULL : (const int *)s->d_truth;
+      if (truth != NULL) {
+        rc = csgpu_internal_eval_list(s->m, (const csgpu_val *)s->d_child_states, s->d_complete_list,
+                                      (const uint64_t *)(s->d_counters + C_COMPLETE), complete, s->d_truth, NULL);
+        if (rc != CSGPU_OK) return rc;
+      }
       hipLaunchKernelGGL(cs_accept, dim3((unsigned)((complete + SB - 1) / SB)), dim3(SB), 0, 0, s->d_child_states,
-                         s->d_truth, (int)complete, n, s->objective, s->obj_var, s->d_counters, s->d_solutions,
+                         truth, (int)complete, n, s->objective, s->obj_var, s->d_counters, s->d_solutions,
                          (long long)s->max_solutions, (const int *)s->d_complete_list);
     } else {
       /* MIN / MAX keep the complete children of the iteration together: cs_pick_best looks at them one host

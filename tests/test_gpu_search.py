@@ -466,3 +466,22 @@ def test_the_engine_applies_the_incumbent_like_the_reference_unit_vectors():
         st = s.run()
         assert st["done"] == 1 and st["best"] == best
         s.close()
+
+
+def test_complete_nodes_of_a_ne_network_need_no_root_evaluation(monkeypatch):
+    """ALL on pure != networks: the engine counts complete consistent children as solutions without evaluating the root
+    (a clause between two valued variables was revised when the second became a value); with CSGPU_SEARCH_EVAL=1 it
+    evaluates them all the same -- same solutions, nodes and cuts, and the stored rows satisfy every clause"""
+    from csolve_amd import problems
+    for text in (problems.queens(9, "ALL"), problems.offsets(7, 6, 3).replace("ANY;", "ALL;", 1)):
+        runs = []
+        for ev in ("0", "1"):
+            monkeypatch.setenv("CSGPU_SEARCH_EVAL", ev)
+            model, s, st = _solve(text)
+            assert st["done"] == 1
+            runs.append((st["solutions"], st["nodes"], st["cuts"]))
+            rows = s.solutions(64)
+            for row in rows:
+                truth = model.eval_root(torch.from_numpy(np.stack([row, row], 1)[None].astype(np.int32)).cuda())
+                assert int(truth[0]) == 1
+        assert runs[0] == runs[1] and runs[0][0] > 0, runs

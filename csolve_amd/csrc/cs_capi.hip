@@ -693,9 +693,12 @@ extern "C" int csgpu_model_finalize(csgpu_model *m) {
         break;
       }
     }
-    if (m->lds_waves < 16 && 8 * lds_slice <= 160u * 1024u) {
-      /* the lists leave LDS for a few waves only: keep them in device memory (L2-resident, every workgroup reads the
-       * same few tens of KB) and give LDS to the node slices -- workgroups of 8 waves, as many per CU as fit */
+    const char *force = getenv("CSGPU_K2_ADJ"); /* "global": measurement override */
+    const int want_global = force != NULL && force[0] == 'g';
+    if (want_global && 8 * lds_slice <= 160u * 1024u) {
+      /* the lists in device memory (L2-resident) and LDS for the node slices only: 24 waves per CU instead of 16 on
+       * the 25x25 sudoku network -- and 1.23 ms instead of 0.75 ms for 2^18 nodes: the two-byte gathers through L2
+       * cost more than the extra waves hide.  Kept for measurements; never chosen automatically. */
       m->lds_adj_global = 1;
       m->lds_waves = 8;
       m->lds_bytes = 8 * lds_slice;

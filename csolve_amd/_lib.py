@@ -124,6 +124,7 @@ def load_library():
     L.csgpu_search_solutions.restype = i64
     L.csgpu_propagate_one.argtypes = [vp, vp, Node, vp, C.POINTER(Result)]
     L.csgpu_propagate_one_traced.argtypes = [vp, vp, Node, vp, C.POINTER(Result), vp, i32, C.POINTER(i32)]
+    L.csgpu_propagate_one_causes.argtypes = [vp, vp, Node, vp, C.POINTER(Result), vp, i32, C.POINTER(i32)]
     L.csgpu_propagate_values.argtypes = [vp, vp, i32, vp, i32, vp, vp]
     L.csgpu_model_root_propagate_limit.argtypes = [vp, i64, C.POINTER(i32), C.POINTER(i32)]
     _lib = L

@@ -98,6 +98,18 @@ struct csgpu_model {
 
 extern "C" const char *csgpu_last_error(void) { return g_err; }
 
+/* Wait for the null stream by polling.  The single-node entries (the drop-in's calls) are a launch of a few
+ * microseconds followed by a wait: hipStreamSynchronize in a process that has not asked for spinning blocks in the
+ * kernel driver and is woken 50-100 us later (the reference's driver linked on this library measured 75 us per call
+ * where a python loop, whose runtime spins, measured 19 us for the same calls). */
+static int wait_null_stream(void) {
+  for (;;) {
+    const hipError_t e = hipStreamQuery(NULL);
+    if (e == hipSuccess) return CSGPU_OK;
+    if (e != hipErrorNotReady) return set_err(CSGPU_E_HIP, "hipStreamQuery: %s", hipGetErrorString(e));
+  }
+}
+
 extern "C" int csgpu_device_count(void) {
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
@@ -562,6 +574,21 @@ static const void *ne_shave_kernel(int width, int n_vars, int slots, int full) {
 #undef CS_PICK_F
 }
 
+/* its tracing variant for single nodes (run-time slot count, guarded lanes: six instantiations in all) */
+static const void *ne_shave_trace_kernel(int width, int n_vars) {
+  const int chunks = (n_vars + CS_WAVE - 1) / CS_WAVE;
+  const int r = chunks <= 1 ? 1 : (chunks <= 2 ? 2 : 4);
+#define CS_PICK(E)                                                                                 \
+  switch (r) {                                                                                     \
+  case 1: return (const void *)cs_propagate_ne_shave<E, 1, 0, false, true>;                         \
+  case 2: return (const void *)cs_propagate_ne_shave<E, 2, 0, false, true>;                         \
+  default: return (const void *)cs_propagate_ne_shave<E, 4, 0, false, true>;                        \
+  }
+  if (width == 1) { CS_PICK(unsigned char) }
+  CS_PICK(unsigned short)
+#undef CS_PICK
+}
+
 /* kernel 5: kernel 4 for small models, 64 / n_vars (2 or 4) nodes per wave; needs the 8-bit dense table (its
  * 16-bit LDS copy is relative to the pushing variable, cs_kernels.hip.h) */
 static int packed_nodes_per_wave(int fw, int n_vars, int dense_width) {
@@ -767,6 +794,7 @@ extern "C" int csgpu_model_finalize(csgpu_model *m) {
               return rc;
           for (int full = 0; full < 2; full++)
             if ((rc = lds_limit(bytes, ne_shave_kernel(m->img->dense_width, h->n_vars, m->img->dense_slots, full)))) return rc;
+          if ((rc = lds_limit(bytes, ne_shave_trace_kernel(m->img->dense_width, h->n_vars)))) return rc;
           HIP_TRY(hipMalloc((void **)&m->d_tickets, (size_t)CS_TICKET_SLOTS * CS_TICKET_SLOT_WORDS * sizeof(unsigned)));
           HIP_TRY(hipMemset(m->d_tickets, 0, (size_t)CS_TICKET_SLOTS * CS_TICKET_SLOT_WORDS * sizeof(unsigned)));
           m->ticket_slots = CS_TICKET_SLOTS;
@@ -940,8 +968,11 @@ static int launch_shave(const csgpu_model *m, const csgpu_val *d_states_in, cons
   const int *root_lo_d = m->d_root_lo, *sym_off = m->d_sym_off;
   long long nb_d = (long long)batch;
   unsigned *tickets = getenv("CSGPU_SHAVE_STATIC") != NULL ? NULL : ticket_slot((csgpu_model *)m, stream);
+  int4 *no_trace = NULL;
+  unsigned *no_trace_n = NULL;
+  unsigned no_trace_cap = 0u;
   void *args[] = { &n, &tab_d, &slots, &dmin_d, &root_lo_d, &sym_off, &d_states_in, &d_nodes, &d_states_out, &d_results,
-                   &nb_d, &d_batch, &csz, &tickets };
+                   &nb_d, &d_batch, &csz, &tickets, &no_trace, &no_trace_n, &no_trace_cap };
   const int chunks_v = (n + CS_WAVE - 1) / CS_WAVE;
   const int lanes = (chunks_v <= 1 ? 1 : (chunks_v <= 2 ? 2 : 4)) * CS_WAVE;
   HIP_TRY(hipLaunchKernel(ne_shave_kernel(m->img->dense_width, n, slots, n == lanes), dim3((unsigned)g),
@@ -1320,7 +1351,7 @@ extern "C" int csgpu_propagate_values(const csgpu_model *cm, const csgpu_val *st
   int rc = csgpu_propagate_batch(m, (const csgpu_val *)m->d_values, (const csgpu_node *)(m->d_values + off_nodes),
                                  (csgpu_val *)(m->d_values + off_out), (csgpu_result *)(m->d_values + off_res), count, NULL);
   if (rc != CSGPU_OK) return rc;
-  HIP_TRY(hipStreamSynchronize(NULL));
+  { const int rcw = wait_null_stream(); if (rcw != CSGPU_OK) return rcw; }
   memcpy(results, m->h_values + off_res, (size_t)count * sizeof *results);
   memcpy(states_out, m->h_values + off_out, (size_t)count * row);
   return CSGPU_OK;
@@ -1358,7 +1389,7 @@ extern "C" int csgpu_propagate_one_traced(const csgpu_model *cm, const csgpu_val
   void *dev = NULL;
   HIP_TRY(hipHostGetDevicePointer(&dev, m->h_trace, 0));
   tab.trace_log = (int4 *)dev;
-  tab.trace_n = (unsigned *)((int32_t *)dev + (size_t)cap * 4);
+  tab.trace_n = (unsigned *)((int32_t *)dev + (size_t)m->trace_cap * 4); /* where h_trace_n points */
   tab.trace_cap = (unsigned)cap;
   const size_t lds = m->slice * CS_WAVES_PER_BLOCK;
   int rc = lds_limit(lds, (const void *)cs_propagate_events<true, false, true>);
@@ -1367,12 +1398,62 @@ extern "C" int csgpu_propagate_one_traced(const csgpu_model *cm, const csgpu_val
                      (const cs_val *)m->d_one_in, (const cs_node_in *)m->d_one_node, (cs_val *)m->d_one_out,
                      (cs_node_out *)m->d_one_res, 1ll, (const unsigned long long *)NULL);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(NULL));
+  { const int rcw = wait_null_stream(); if (rcw != CSGPU_OK) return rcw; }
   memcpy(result, m->h_one + part + 64, sizeof *result);
   if (result->status >= 0) memcpy(state_out, m->h_one + part + 128, nbytes);
   const unsigned n = *m->h_trace_n;
   *count = (int32_t)n;
   memcpy(trace, m->h_trace, (size_t)(n < (unsigned)cap ? n : (unsigned)cap) * 16);
+  return CSGPU_OK;
+}
+
+/* One node of a pure != network with its trail as causes: kernel 7's tracing variant, one wave. */
+extern "C" int csgpu_propagate_one_causes(const csgpu_model *cm, const csgpu_val *state, csgpu_node node,
+                                          csgpu_val *state_out, csgpu_result *result, int32_t *trace, int32_t cap,
+                                          int32_t *count) {
+  csgpu_model *m = const_cast<csgpu_model *>(cm);
+  if (m == NULL || state == NULL || state_out == NULL || result == NULL || trace == NULL || cap < 1 || count == NULL)
+    return set_err(CSGPU_E_ARG, "bad argument");
+  if (!m->finalized) return set_err(CSGPU_E_STATE, "model is not finalized");
+  if (!m->dense_waves) return set_err(CSGPU_E_LIMIT, "model does not qualify for the interval-only shaving kernel");
+  if (m->trace_cap < cap) {
+    if (m->h_trace != NULL) (void)hipHostFree(m->h_trace);
+    m->h_trace = NULL;
+    HIP_TRY(hipHostMalloc((void **)&m->h_trace, (size_t)cap * 16 + 16, hipHostMallocMapped));
+    m->h_trace_n = (unsigned *)(m->h_trace + (size_t)cap * 4);
+    m->trace_cap = cap;
+  }
+  const size_t nbytes = (size_t)m->host->n_vars * sizeof(cs_val);
+  const size_t part = (nbytes + 63) & ~(size_t)63;
+  node.parent = 0;
+  memcpy(m->h_one, state, nbytes);
+  memcpy(m->h_one + part, &node, sizeof node);
+  *m->h_trace_n = 0u;
+  void *dev = NULL;
+  HIP_TRY(hipHostGetDevicePointer(&dev, m->h_trace, 0));
+  int4 *d_trace = (int4 *)dev;
+  unsigned *d_trace_n = (unsigned *)((int32_t *)dev + (size_t)m->trace_cap * 4);
+  unsigned ucap = (unsigned)cap;
+  int n = m->host->n_vars, slots = m->img->dense_slots, dmin_d = m->img->dense_dmin, csz = 1;
+  const void *tab_d = m->d_dense_tab;
+  const int *root_lo_d = m->d_root_lo, *sym_off = m->d_sym_off;
+  long long nb_d = 1;
+  const uint64_t *d_batch = NULL;
+  unsigned *tickets = NULL;
+  const csgpu_val *d_in = (const csgpu_val *)m->d_one_in;
+  const csgpu_node *d_node = (const csgpu_node *)m->d_one_node;
+  csgpu_val *d_out = (csgpu_val *)m->d_one_out;
+  csgpu_result *d_res = (csgpu_result *)m->d_one_res;
+  void *args[] = { &n, &tab_d, &slots, &dmin_d, &root_lo_d, &sym_off, &d_in, &d_node, &d_out, &d_res,
+                   &nb_d, &d_batch, &csz, &tickets, &d_trace, &d_trace_n, &ucap };
+  HIP_TRY(hipLaunchKernel(ne_shave_trace_kernel(m->img->dense_width, n), dim3(1), dim3((unsigned)(m->dense_waves * CS_WAVE)),
+                          args, m->dense_bytes, (hipStream_t)NULL));
+  { const int rcw = wait_null_stream(); if (rcw != CSGPU_OK) return rcw; }
+  memcpy(result, m->h_one + part + 64, sizeof *result);
+  if (result->status >= 0) memcpy(state_out, m->h_one + part + 128, nbytes);
+  const unsigned made = *m->h_trace_n;
+  *count = (int32_t)made;
+  memcpy(trace, m->h_trace, (size_t)(made < (unsigned)cap ? made : (unsigned)cap) * 16);
   return CSGPU_OK;
 }
 
@@ -1388,7 +1469,7 @@ extern "C" int csgpu_propagate_one(const csgpu_model *m, const csgpu_val *state,
   int rc = csgpu_propagate_batch(m, (const csgpu_val *)m->d_one_in, (const csgpu_node *)m->d_one_node,
                                  (csgpu_val *)m->d_one_out, (csgpu_result *)m->d_one_res, 1, NULL);
   if (rc != CSGPU_OK) return rc;
-  HIP_TRY(hipStreamSynchronize(NULL)); /* one launch, one wait: the kernel worked on the mapped host buffers */
+  { const int rcw = wait_null_stream(); if (rcw != CSGPU_OK) return rcw; } /* one launch, one wait: the kernel worked on the mapped host buffers */
   memcpy(result, m->h_one + part + 64, sizeof *result);
   if (result->status >= 0) memcpy(state_out, m->h_one + part + 128, nbytes);
   return CSGPU_OK;

@@ -10,9 +10,10 @@
  *   - conflict_reset() at the entry of propagate_clauses (reference src/propagate.c:496).
  *   - on inconsistency the variable whose domain emptied gets prio++ and strategy_var_order_update()
  *     (propagate_term_confl, reference src/propagate.c:33-41): the device reports one such variable.  The
- *     reference additionally bumps every variable on its recursion stack (propagate.c:44-54); that stack is
- *     a property of its depth-first revision order and has no counterpart here, so default-flag (-f true)
- *     runs are valid searches but not call-for-call the reference's; -f false runs are.
+ *     reference additionally bumps every variable on its recursion stack (propagate.c:44-54): the chain of
+ *     variables from the assignment to the failure.  The device's trail gives such a chain (bump_failure_chain /
+ *     deliver_causes below); it need not be the one the depth-first order walks, so default-flag (-f true) runs
+ *     are valid searches of about the reference's length but not call for call the reference's; -f false runs are.
  *   - propagate(root, limit): at most limit + 1 device sweeps (csgpu_model_root_propagate_limit).
  * Sibling batching (CSOLVE_DROPIN_SIBLINGS=1): the driver tries the values of a variable one after the other
  * (step_val, csolve.c:331-338), each through bind + propagate_clauses.  The first such call propagates the next
@@ -37,6 +38,7 @@ extern void strategy_var_order_update(struct env_t *e);
 extern void conflict_reset(void);
 extern void conflict_create(struct env_t *var, const struct wand_expr_t *clause); /* conflict.c:319-361 */
 extern int strategy_create_conflicts(void);                                      /* strategy.c (bool) */
+extern _Bool strategy_prefer_failing(void);                                      /* strategy.c:49 */
 extern void print_fatal(const char *fmt, ...);
 extern uint64_t props;
 
@@ -216,7 +218,8 @@ static int32_t g_n_clause_ptr;
 static size_t g_attached_lists;                 /* entries of all clause lists at attach time: they only grow */
 static int32_t *g_trail;
 #define CS_TRAIL_CAP 16384
-static uint64_t g_conflicts_offered, g_reattached;
+static uint64_t g_conflicts_offered, g_reattached, g_chain_bumps;
+static int32_t *g_clause_vars; /* [2 * clauses]: the two variables of a binary clause, -1 otherwise */
 static uint64_t g_calls[4];
 static uint64_t g_sib_launches, g_sib_served; /* sibling batches launched, calls served from one */
 
@@ -247,6 +250,7 @@ static struct {
 
 void csolve_dropin_sibling_counters(uint64_t out[2]) { out[0] = g_sib_launches; out[1] = g_sib_served; }
 void csolve_dropin_learning_counters(uint64_t out[2]) { out[0] = g_conflicts_offered; out[1] = g_reattached; }
+uint64_t csolve_dropin_chain_bumps(void) { return g_chain_bumps; }
 
 /* where the shim's time goes: [0] attach (flatten + finalize + upload), [1] inside the device calls of
  * propagate_clauses, [2] the rest of propagate_clauses (state marshalling, bind() replay) */
@@ -349,6 +353,17 @@ static int attach(struct env_t *env, size_t size, struct constr_t *root, int at_
     }
   }
   f.m->list_off[size] = (int32_t)total;
+  /* the two variables of every binary clause (for the failure chain below), from the lists */
+  free(g_clause_vars);
+  g_clause_vars = (int32_t *)malloc((size_t)(f.m->n_clauses ? f.m->n_clauses : 1) * 2 * sizeof(int32_t));
+  for (int32_t c = 0; c < 2 * f.m->n_clauses; c++) g_clause_vars[c] = -1;
+  for (size_t i = 0; i < size; i++)
+    for (int32_t k = f.m->list_off[i]; k < f.m->list_off[i + 1]; k++) {
+      int32_t *cv = &g_clause_vars[2 * f.m->list[k]];
+      if (cv[0] == -1) cv[0] = (int32_t)i;
+      else if (cv[0] >= 0 && cv[1] == -1 && cv[0] != (int32_t)i) cv[1] = (int32_t)i;
+      else if (cv[0] != (int32_t)i && cv[1] != (int32_t)i) cv[0] = cv[1] = -2; /* three or more variables */
+    }
   pmap_free(&clause_ids);
   flat_done(&f);
 
@@ -456,16 +471,98 @@ static int learning(void) {
   return on && strategy_create_conflicts();
 }
 
+/* The failure chain (the driver's -f true, its default).  When a node fails the reference bumps the priority of the
+ * variable whose domain emptied (propagate_term_confl, propagate.c:33-41) AND of every variable on its recursion
+ * stack (propagate_term_recurse, propagate.c:44-54): the variables whose narrowing led, one through the next, from
+ * the assignment to the failure.  The device's trail names the clause behind every narrowing, so such a chain can
+ * be read off it: from the failing variable to the other variable of the clause that failed it, to the clause that
+ * had narrowed THAT one, and so on back to the assignment.  It is a causal chain of the same kind, not necessarily
+ * the one the depth-first order would have walked.  CSOLVE_DROPIN_CHAIN=0 switches it off. */
+static int chain_mode(void) {
+  static int on = -1;
+  if (on < 0) {
+    const char *e = getenv("CSOLVE_DROPIN_CHAIN");
+    on = e == NULL || atoi(e) != 0;
+  }
+  return on && strategy_prefer_failing();
+}
+
+static void bump_failure_chain(int32_t assigned, int32_t fail_var, int32_t fail_clause, int32_t fail_index) {
+  int32_t v = fail_var, c = fail_clause, at = fail_index;
+  for (size_t steps = 0; steps < g_size; steps++) {
+    if (c < 0 || c >= g_n_clause_ptr) return;
+    const int32_t a = g_clause_vars[2 * c], b = g_clause_vars[2 * c + 1];
+    if (a < 0 || b < 0) return; /* not a binary clause: no single predecessor */
+    const int32_t u = a == v ? b : (b == v ? a : -1);
+    if (u < 0 || u == assigned) return; /* the driver bumps the assigned variable itself (csolve.c:462) */
+    int32_t found = -1;
+    for (int32_t r = at - 1; r >= 0; r--)
+      if (g_trail[4 * r] == u && g_trail[4 * r + 1] != 2) { found = r; break; }
+    if (found < 0) return; /* u had its value before this node */
+    g_env[u].prio++;
+    strategy_var_order_update(&g_env[u]);
+    g_chain_bumps++;
+    v = u;
+    c = g_trail[4 * found + 3];
+    at = found;
+  }
+}
+
+/* the same with the trail of kernel 7 (causes are variables, no clauses: for the chain alone, not for learning) */
+static prop_result_t deliver_causes(int32_t var, const csgpu_result *res, const csgpu_val *out, int32_t count) {
+  props += (uint64_t)res->props;
+  if (res->status >= 0) {
+    for (size_t i = 0; i < g_size; i++)
+      if (out[i].lo != g_state[i].lo || out[i].hi != g_state[i].hi) {
+        struct val_t v = { out[i].lo, out[i].hi };
+        bind(&g_env[i], v, NULL);
+      }
+    return res->props;
+  }
+  /* the failure: the first record whose move empties its variable */
+  const int32_t have = count < CS_TRAIL_CAP ? count : CS_TRAIL_CAP;
+  int32_t fail_var = -1, fail_at = -1;
+  for (int32_t r = 0; r < have && fail_var < 0; r++) {
+    const int32_t v = g_trail[4 * r], kind = g_trail[4 * r + 1], bound = g_trail[4 * r + 2];
+    if (v < 0 || (size_t)v >= g_size) continue;
+    if (kind == 0 && bound > g_state[v].lo) g_state[v].lo = bound;
+    else if (kind == 1 && bound < g_state[v].hi) g_state[v].hi = bound;
+    if (g_state[v].lo > g_state[v].hi) { fail_var = v; fail_at = r; }
+  }
+  if (fail_var < 0 && res->rounds >= 0 && (size_t)res->rounds < g_size) fail_var = res->rounds;
+  if (fail_var >= 0) {
+    g_env[fail_var].prio++;
+    strategy_var_order_update(&g_env[fail_var]);
+    /* from the failing variable to the variable that moved its bound, to the one that had moved THAT one's, ... */
+    int32_t v = fail_var, at = fail_at;
+    for (size_t steps = 0; at >= 0 && steps < g_size; steps++) {
+      const int32_t u = g_trail[4 * at + 3];
+      if (u < 0 || (size_t)u >= g_size || u == var) break; /* the driver bumps the assigned variable itself */
+      int32_t found = -1;
+      for (int32_t r = at - 1; r >= 0; r--)
+        if (g_trail[4 * r] == u) { found = r; break; }
+      if (found < 0) break; /* u had its value before this node */
+      g_env[u].prio++;
+      strategy_var_order_update(&g_env[u]);
+      g_chain_bumps++;
+      v = u;
+      at = found;
+    }
+    (void)v;
+  }
+  return PROP_ERROR;
+}
+
 static prop_result_t deliver_traced(int32_t var, const csgpu_result *res, const csgpu_val *out, int32_t count) {
   props += (uint64_t)res->props;
   const int32_t have = count < CS_TRAIL_CAP ? count : CS_TRAIL_CAP;
-  int32_t fail_var = -1;
+  int32_t fail_var = -1, fail_clause_id = -1, fail_index = -1;
   const struct wand_expr_t *fail_clause = NULL;
   for (int32_t r = 0; r < have; r++) {
     const int32_t v = g_trail[4 * r], kind = g_trail[4 * r + 1], bound = g_trail[4 * r + 2], c = g_trail[4 * r + 3];
     const struct wand_expr_t *w = c >= 0 && c < g_n_clause_ptr ? g_clause_ptr[c] : NULL;
     if (kind == 2) { /* the device saw the node fail here */
-      if (v >= 0 && (size_t)v < g_size) { fail_var = v; fail_clause = w; }
+      if (v >= 0 && (size_t)v < g_size) { fail_var = v; fail_clause = w; fail_clause_id = c; fail_index = r; }
       break;
     }
     if (v < 0 || (size_t)v >= g_size) continue;
@@ -476,6 +573,8 @@ static prop_result_t deliver_traced(int32_t var, const csgpu_result *res, const 
     if (now.lo > now.hi) { /* propagate_term finds the intersection empty before it binds (propagate.c:64-70) */
       fail_var = v;
       fail_clause = w;
+      fail_clause_id = c;
+      fail_index = r;
       break;
     }
     bind(&g_env[v], now, w);
@@ -485,7 +584,8 @@ static prop_result_t deliver_traced(int32_t var, const csgpu_result *res, const 
     if (fail_var >= 0) { /* propagate_term_confl (propagate.c:33-41) */
       g_env[fail_var].prio++;
       strategy_var_order_update(&g_env[fail_var]);
-      if (fail_clause != NULL && count <= CS_TRAIL_CAP) {
+      if (chain_mode() && fail_index >= 0 && count <= CS_TRAIL_CAP) bump_failure_chain(var, fail_var, fail_clause_id, fail_index);
+      if (learning() && fail_clause != NULL && count <= CS_TRAIL_CAP) {
         g_conflicts_offered++;
         conflict_create(&g_env[fail_var], fail_clause);
       }
@@ -541,7 +641,7 @@ static prop_result_t propagate_clauses_timed(const struct clause_list_t *clauses
    * value, so on its depth-first searches speculation costs more than it saves */
   if (batching < 0) batching = getenv("CSOLVE_DROPIN_SIBLINGS") != NULL && atoi(getenv("CSOLVE_DROPIN_SIBLINGS")) != 0;
   const int32_t k = g_state[var].lo;
-  if (batching && !learning() && g_state[var].lo == g_state[var].hi) {
+  if (batching && !learning() && !chain_mode() && g_state[var].lo == g_state[var].hi) {
     /* the iteration this call belongs to: same variable, every OTHER domain what it was */
     int same = g_sib.valid && g_sib.var == var && k >= g_sib.lo && k <= g_sib.hi;
     for (size_t i = 0; i < g_size && same; i++)
@@ -606,7 +706,17 @@ static prop_result_t propagate_clauses_timed(const struct clause_list_t *clauses
   csgpu_result res;
   TRACE("[dropin] propagate_clauses var=%d [%d,%d]\n", node.var, node.lo, node.hi);
   const double td = now_s();
-  if (learning()) {
+  if (!learning() && chain_mode() && csgpu_model_qualifies(g_model, 7) == 1) {
+    /* pure != network: kernel 7's trail, at the latency of the untraced call */
+    if (g_trail == NULL) g_trail = (int32_t *)malloc((size_t)CS_TRAIL_CAP * 4 * sizeof(int32_t));
+    int32_t count = 0;
+    if (csgpu_propagate_one_causes(g_model, g_state, node, g_out, &res, g_trail, CS_TRAIL_CAP, &count) != CSGPU_OK)
+      fatal_gpu("propagate_clauses");
+    g_seconds[1] += now_s() - td;
+    TRACE("[dropin]   -> status %d props %d, %d cause records\n", res.status, res.props, count);
+    return deliver_causes(var, &res, g_out, count);
+  }
+  if (learning() || chain_mode()) {
     if (g_trail == NULL) g_trail = (int32_t *)malloc((size_t)CS_TRAIL_CAP * 4 * sizeof(int32_t));
     int32_t count = 0;
     if (csgpu_propagate_one_traced(g_model, g_state, node, g_out, &res, g_trail, CS_TRAIL_CAP, &count) != CSGPU_OK)

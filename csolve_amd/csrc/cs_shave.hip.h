@@ -96,12 +96,17 @@ __device__ __forceinline__ int cs_writelane_at(int lane, int v, int x) {
 
 /* SL: slots per pair known at compile time (1 = alldiff-style, 3 = queens), 0 = run-time loop.
  * FULL: n == 64 R, every lane register holds a variable: loads and stores are unconditional. */
-template <typename E, int R, int SL, bool FULL>
+/* TRACE (single-node launches only, csgpu_propagate_one_causes): every bound move is recorded as
+ * {variable, 0 = lower / 1 = upper bound, new bound, the valued variable that forbade the old one} in `trace`,
+ * in the order the wave made them -- the trail the reference keeps through bind() (csolve.h:73-79), with the cause
+ * as a variable instead of a clause (on a != network the clause is the pair). */
+template <typename E, int R, int SL, bool FULL, bool TRACE = false>
 __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_shave(
     int n, const E *__restrict__ tab_g, int slots, int dmin, const int *__restrict__ root_lo,
     const int *__restrict__ sym_off, const cs_val *__restrict__ states_in, const cs_node_in *__restrict__ nodes,
     cs_val *__restrict__ states_out, cs_node_out *__restrict__ results, long long batch,
-    const unsigned long long *__restrict__ batch_dev, int csz /* 1 or 2 nodes per chunk */, unsigned *tickets) {
+    const unsigned long long *__restrict__ batch_dev, int csz /* 1 or 2 nodes per chunk */, unsigned *tickets,
+    int4 *__restrict__ trace, unsigned *__restrict__ trace_n, unsigned trace_cap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
   typedef unsigned long long u64;
   constexpr int W = CS_WAVE * R; /* columns of the table */
@@ -257,6 +262,15 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_shave(
         push[r] = val[r] & ~pushed[r];
       }
 
+      unsigned tcount = 0u; /* TRACE: records made so far (one wave, one node: a scalar) */
+      /* the lanes of `mask` (register r2) record their new bound, moved because of variable `cause` */
+      auto trace_lanes = [&](u64 mask, int r2, int kind, int value, int cause) {
+        if (mask == 0ull) return;
+        const unsigned at = tcount + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+        if (((mask >> lane) & 1ull) != 0ull && at < trace_cap)
+          trace[at] = make_int4(lane + r2 * CS_WAVE, kind, value + b0[r2], cause);
+        tcount += (unsigned)__builtin_popcountll(mask);
+      };
       int rounds = 0, revisions = 0;
       /* PUSH(u): the variable `ul` of register r is the value cd + dmin; every lane moves a bound that equals the
        * value u forbids for it by one and is dirty then */
@@ -292,8 +306,13 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_shave(
         }
 #pragma unroll
         for (int r2 = 0; r2 < R; r2++) {
-          dl[r2] |= __ballot(rlo[r2] != plo[r2]);
-          dh[r2] |= __ballot(rhi[r2] != phi[r2]);
+          const u64 ml = __ballot(rlo[r2] != plo[r2]), mh = __ballot(rhi[r2] != phi[r2]);
+          dl[r2] |= ml;
+          dh[r2] |= mh;
+          if (TRACE) {
+            trace_lanes(ml, r2, 0, rlo[r2], ul + r * CS_WAVE);
+            trace_lanes(mh, r2, 1, rhi[r2], ul + r * CS_WAVE);
+          }
         }
       };
       /* the fixpoint; returns -1, or a variable whose domain has become empty (what the reference's
@@ -377,6 +396,7 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_shave(
                   for (int k = 0; k < (SL ? SL : 1); k++)
 #pragma unroll
                     for (int r2 = 0; r2 < R; r2++) e[k][r2] = (int)row[k * W + r2 * CS_WAVE];
+                  int cause = -1; /* TRACE: a valued variable that forbids the candidate */
 #pragma unroll
                   for (int r2 = 0; r2 < R; r2++) {
                     const int t = ckw - rlo[r2];
@@ -384,6 +404,7 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_shave(
 #pragma unroll
                     for (int k = 0; k < (SL ? SL : 1); k++) h |= __ballot(e[k][r2] == t);
                     hit |= h & val[r2];
+                    if (TRACE && cause < 0 && (h & val[r2]) != 0ull) cause = __builtin_ctzll(h & val[r2]) + r2 * CS_WAVE;
                   }
                   if (hit == 0ull) continue; /* supported: the common case */
                   /* the bound moves on, one value (one PROPS) at a time, until it is supported or passes the other */
@@ -405,6 +426,7 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_shave(
                   }
                   cand += side == 0 ? step : -step;
                   if (lane == wl) { if (side == 0) rlo[r] = cand; else rhi[r] = cand; }
+                  if (TRACE) trace_lanes(1ull << wl, r, side, cand, cause);
                   /* a bound that passed the other one is the failure: noticed after the loops (no exit from in here) */
                   if (side == 0 ? cand > other : cand < other) fail_v = wl + r * CS_WAVE;
                   if (cand == other) val[r] |= 1ull << wl; /* counts for the verifications that follow */
@@ -412,12 +434,16 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_shave(
                   /* run-time slot count: the row is re-read per candidate */
                   const int other = __builtin_amdgcn_readlane(side == 0 ? rhi[r] : rlo[r], wl);
                   int step = 0;
+                  int cause = -1;
                   for (;;) {
                     hit = 0ull;
                     for (int k = 0; k < slots; k++) {
 #pragma unroll
-                      for (int r2 = 0; r2 < R; r2++)
-                        hit |= __ballot((int)row[k * W + r2 * CS_WAVE] == ckw + (side == 0 ? step : -step) - rlo[r2]) & val[r2];
+                      for (int r2 = 0; r2 < R; r2++) {
+                        const u64 h = __ballot((int)row[k * W + r2 * CS_WAVE] == ckw + (side == 0 ? step : -step) - rlo[r2]) & val[r2];
+                        hit |= h;
+                        if (TRACE && cause < 0 && h != 0ull) cause = __builtin_ctzll(h) + r2 * CS_WAVE;
+                      }
                     }
                     if (hit == 0ull) break;
                     step++;
@@ -426,6 +452,7 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_shave(
                   if (step != 0) {
                     cand += side == 0 ? step : -step;
                     if (lane == wl) { if (side == 0) rlo[r] = cand; else rhi[r] = cand; }
+                    if (TRACE) trace_lanes(1ull << wl, r, side, cand, cause);
                     if (side == 0 ? cand > other : cand < other) fail_v = wl + r * CS_WAVE;
                     if (cand == other) val[r] |= 1ull << wl;
                   }
@@ -450,6 +477,7 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_shave(
       };
       const int fail_var = fixpoint();
       const int failed = fail_var >= 0;
+      if (TRACE && lane == 0) *trace_n = tcount;
       if (rounds != 0) __builtin_amdgcn_s_setprio(0);
 
       int open_vars = 0, shaved = 0;

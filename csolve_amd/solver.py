@@ -261,6 +261,20 @@ class Model:
         return res.status, res.props, out
 
 
+    def propagate_one_causes(self, state: np.ndarray, var: int, lo: int, hi: int, cap: int = 4096):
+        """One node of a pure != network with the cause of every bound move (csgpu_propagate_one_causes).
+        -> (status, props, fixpoint or None, trace [k, 4] = {variable, 0 lo / 1 hi, new bound, causing variable})"""
+        state = np.ascontiguousarray(state, dtype=np.int32)
+        out = np.empty_like(state)
+        res = Result()
+        trace = np.empty((cap, 4), dtype=np.int32)
+        cnt = C.c_int32()
+        check(load_library().csgpu_propagate_one_causes(self._h, state.ctypes.data, Node(var, lo, hi, 0), out.ctypes.data,
+                                                        C.byref(res), trace.ctypes.data, cap, C.byref(cnt)))
+        if cnt.value > cap:
+            raise OverflowError(f"{cnt.value} trace records, room for {cap}")
+        return res.status, res.props, (out if res.status >= 0 else None), trace[: cnt.value].copy()
+
     def propagate_one_traced(self, state: np.ndarray, var: int, lo: int, hi: int, cap: int = 4096):
         """One node with its trail (csgpu_propagate_one_traced).
         -> (status, props, fixpoint or None, trace [k, 4] = {variable, 0 lo / 1 hi / 2 failure, new bound, clause})"""

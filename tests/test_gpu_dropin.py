@@ -72,18 +72,26 @@ def test_reference_driver_with_default_flags_on_gpu_propagator(n, tmp_path):
     from csolve_amd import problems
     path = tmp_path / f"queens{n}.txt"
     path.write_text(problems.queens(n))
-    stats, used, sol = _run(str(path), ["-c", "false"], env={"CSOLVE_DROPIN_SIBLINGS": "1"})
+    # (a) without the failure chain (only the emptied variable is bumped): sibling batches serve the same search
+    nochain = {"CSOLVE_DROPIN_CHAIN": "0"}
+    stats, used, sol = _run(str(path), ["-c", "false"], env=dict(nochain, CSOLVE_DROPIN_SIBLINGS="1"))
     assert stats["solutions"] == 1 and sol is not None and _queens_valid(sol, n)
     assert used["sibling_batches"] > 0 and used["served_from_batch"] > 0
     assert used["sibling_batches"] + used["served_from_batch"] <= used["propagate_clauses"]
-    assert stats["calls"] < 100000  # the reference needs 430 / 4,045 with its own failure chains
-    plain, used1, sol1 = _run(str(path), ["-c", "false"])  # the default: one node per call
+    assert stats["calls"] < 100000
+    plain, used1, sol1 = _run(str(path), ["-c", "false"], env=nochain)  # one node per call
     assert used1["sibling_batches"] == 0
     for k in ("calls", "cuts", "restarts", "solutions"):
         assert plain[k] == stats[k], k
     assert sol1 == sol
-    again, _, sol2 = _run(str(path), ["-c", "false"])  # and the run is reproducible
-    assert again["calls"] == plain["calls"] and sol2 == sol1
+    # (b) the default: the device's trail gives the chain of variables from the assignment to the failure, and the shim
+    # bumps them as propagate_term_recurse does (propagate.c:44-54).  The search then needs about as many calls as the
+    # reference's own (430 / 4,045 on its depth-first chains; without the chain 2,070 / 3,301), and is reproducible.
+    chain, _, sol3 = _run(str(path), ["-c", "false"])
+    assert chain["solutions"] == 1 and _queens_valid(sol3, n)
+    assert chain["calls"] < plain["calls"] and chain["calls"] < (1000 if n == 64 else 2500), chain
+    again, _, sol2 = _run(str(path), ["-c", "false"])
+    assert again["calls"] == chain["calls"] and sol2 == sol3
 
 
 @pytest.mark.skipif(not os.path.exists(BIN), reason="oracle/_ref/csolve_ref_dropin not built (needs the reference tree)")

@@ -263,3 +263,62 @@ def test_trail_of_one_node(tmp_path):
                 failures += 1
                 assert (trace[:, 1] == 2).any() or (dom[:, 0] > dom[:, 1]).any()
         assert failures > 0
+
+
+def test_causes_of_one_node():
+    """csgpu_propagate_one_causes (kernel 7's tracing variant): replaying the records in order gives the fixpoint, every
+    cause is a neighbour of the moved variable that is a value in the fixpoint (or the assigned variable), a failing
+    node's replay empties a domain, and verdict / fixpoint / PROPS are those of the untraced call"""
+    from csolve_amd import problems
+    from csolve_amd.solver import solve_root
+    from oracle.cs_oracle import Model as OModel, Oracle
+    for text in (problems.queens(12), problems.queens(70), problems.offsets(40, 30, 5), problems.sudoku(3, 0.3, 2)):
+        gm = solve_root(text)
+        if not gm.qualifies(7):
+            continue
+        om = OModel.parse(text)
+        om.set_domains(gm.domains())
+        om.normalize()
+        om.index()
+        neigh = [set() for _ in range(om.n_vars)]
+        members = [set() for _ in range(om.n_clauses)]
+        for v in range(om.n_vars):
+            for i in range(om.view.list_off[v], om.view.list_off[v + 1]):
+                members[om.view.list[i]].add(v)
+        for vs in members:
+            for a in vs:
+                neigh[a] |= vs - {a}
+        orc = Oracle(om)
+        rng = np.random.default_rng(17)
+        parents, nodes = _walk_instances(orc, gm.domains(), rng, 150)
+        failures = 0
+        for v, lo, hi, p in nodes:
+            st, props, out, trace = gm.propagate_one_causes(parents[p], int(v), int(lo), int(hi))
+            st0, props0, out0 = gm.propagate_one(parents[p], int(v), int(lo), int(hi))
+            assert (st < 0) == (st0 < 0)
+            dom = parents[p].copy()
+            dom[v] = (lo, hi)
+            emptied = False
+            for var, kind, bound, cause in trace:
+                assert kind in (0, 1) and 0 <= var < om.n_vars and 0 <= cause < om.n_vars and cause != var
+                # a variable that is a value at the root has no clause list (parser_support.c:341) and so no entry in
+                # `neigh`; as a cause it is legitimate (its value can forbid the value a bound has just moved onto)
+                root = gm.domains()
+                assert cause in neigh[var] or var in neigh[cause] or root[cause, 0] == root[cause, 1] or \
+                    root[var, 0] == root[var, 1], (var, cause)
+                if kind == 0:
+                    assert bound > dom[var, 0]
+                    dom[var, 0] = bound
+                else:
+                    assert bound < dom[var, 1]
+                    dom[var, 1] = bound
+                if dom[var, 0] > dom[var, 1]:
+                    emptied = True
+                    break
+            if st >= 0:
+                assert not emptied and (dom == out).all() and (out == out0).all() and props == props0
+                assert props == len(trace) or props >= len(trace)  # a record may stand for several unit moves
+            else:
+                failures += 1
+                assert emptied
+        assert failures > 0

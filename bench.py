@@ -268,7 +268,8 @@ def search_workload(args, rank, world, local, dist):
         eng.reset()
         sh = ShardedSearch(eng, model.objective, n, rank, world, dist, engine_device="cuda", comm_device=comm,
                            slice_iterations=args.slice or (64 if model.objective == 1 else 256),  # 1 = ALL; a dry rank calls the exchange earlier
-                           seed_states_per_rank=256, low_water=4096, poll_iterations=args.poll)
+                           seed_states_per_rank=256, low_water=4096, poll_iterations=args.poll,
+                           time_limit=args.time_limit if args.time_limit > 0 else None)
         local_stats, totals = sh.run(model.root_state(), args.search_slices if args.search_slices > 0 else 1 << 40)
         return local_stats, totals, sh
 
@@ -317,7 +318,7 @@ def search_workload(args, rank, world, local, dist):
                        "nodes": totals["nodes"], "cuts": totals["cuts"], "props": totals["props"],
                        "iterations": totals["iterations"], "states_moved_between_ranks": int(moved.item()),
                        "nodes_per_rank": share.cpu().tolist(), "comm": args.comm,
-                       "process_group": None if dist is None else dist.get_backend(),
+                       "process_group": None if dist is None else dist.get_backend(), "timeout": bool(totals.get("timeout")),
                        "stopped_after_slices": args.search_slices or None},
             # one entry per rank, last step: idle = share of the time after seeding not spent inside the engine;
             # put = csgpu_search_put (copy + rebuilding the forbidden sets of seeded / stolen states)
@@ -355,6 +356,8 @@ def main():
     ap.add_argument("--workload", choices=["propagate", "search"], default="propagate")
     ap.add_argument("--process-group", action="store_true", help="create the process group even for one rank (the "
                     "collectives of the search workload then run over RCCL / gloo with world size 1)")
+    ap.add_argument("--time-limit", type=float, default=0.0, help="search workload: stop every rank after this many seconds "
+                    "(the reference's -t; 0 = none); the line then says \"timeout\": true and counts what was explored")
     ap.add_argument("--poll", type=int, default=4, help="search workload: iterations between two looks at the node's "
                     "status page")
     ap.add_argument("--search-queens", type=int, default=17, help="queens-N tree of the search workload (ALL: 17 is "

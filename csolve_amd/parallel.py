@@ -55,7 +55,7 @@ class StatusPage:
     timeout flag): a rank reads its neighbours' words between bursts of iterations without any collective, so an
     incumbent bounds the other ranks, and a dry rank's request for work is seen, within one burst rather than one
     slice.  Words are aligned int64, written by exactly one rank each."""
-    WANT, BEST, FOUND, POOL, WORDS = 0, 1, 2, 3, 8
+    WANT, BEST, FOUND, POOL, TIMEOUT, WORDS = 0, 1, 2, 3, 4, 8
 
     def __init__(self, path: str, rank: int, world: int, create: bool):
         import mmap
@@ -96,6 +96,12 @@ class StatusPage:
     def any_found(self):
         return bool(self.words[:, self.FOUND].any())
 
+    def set_timeout(self):
+        self.words[self.rank, self.TIMEOUT] = 1
+
+    def timed_out(self):
+        return bool(self.words[:, self.TIMEOUT].any())
+
     def close(self):
         self.words = None
         try:
@@ -114,6 +120,8 @@ class ShardedSearch:
     poll_iterations: a slice is run in bursts of this many iterations; between bursts the rank looks at the
             node's StatusPage (no collective, no device synchronisation beyond the burst's own).
     status_page: None = use one when all ranks can map the same /dev/shm file (one node), False = never.
+    time_limit: seconds after which the search stops on every rank with what it has (the reference's -t: SIGALRM sets
+            shared()->timeout, which every worker's loop tests, csolve.c:190-203,408); totals["timeout"] tells.
 
     Time accounting (self.seconds): "seed" (expanding the root, done by every rank alike), "busy" (inside
     engine.run with a non-empty pool), "exchange" (collectives, transfers and the wait for the slowest rank),
@@ -124,8 +132,12 @@ class ShardedSearch:
 
     def __init__(self, engine, objective: int, n_vars: int, rank: int, world: int, dist=None,
                  engine_device="cuda", comm_device=None, slice_iterations: int = 64, seed_states_per_rank: int = 64,
-                 low_water: int = 64, poll_iterations: int = 4, status_page=None, seed_on_every_rank: bool = True):
+                 low_water: int = 64, poll_iterations: int = 4, status_page=None, seed_on_every_rank: bool = True,
+                 time_limit: float = None):
         self.engine, self.objective, self.n, self.rank, self.world = engine, objective, n_vars, rank, world
+        self.time_limit = time_limit  # seconds, like the reference's -t (timeout_init / shared()->timeout, csolve.c:190-203,408)
+        self.timed_out = False
+        self._deadline = None
         self.dist = dist
         self.engine_device = engine_device
         self.comm_device = comm_device or engine_device
@@ -244,15 +256,17 @@ class ShardedSearch:
     def _exchange(self, stats):
         """incumbent, termination and work stealing; returns True when the search is over"""
         found = 1 if stats["solutions"] > 0 else 0
-        table = self._gather_words([stats["pool"], stats["best"], found])
+        table = self._gather_words([stats["pool"], stats["best"], found, 1 if self._expired() else 0])
         pools = [int(r[0]) for r in table]
+        if any(int(r[3]) for r in table):  # one rank's clock is everybody's: all stop in the same exchange
+            self.timed_out = True
         if self.objective == OBJ_MIN:
             self.engine.set_best(min(int(r[1]) for r in table))
         elif self.objective == OBJ_MAX:
             self.engine.set_best(max(int(r[1]) for r in table))
         if self.objective == OBJ_ANY and any(int(r[2]) for r in table):
             return True
-        if sum(pools) == 0:
+        if sum(pools) == 0 or self.timed_out:
             return True
         for src, dst, cnt in plan_transfers(pools, self.low_water):
             self.exchanges += 1
@@ -266,6 +280,10 @@ class ShardedSearch:
                 self.dist.recv(buf, src=src)
                 self.engine.put(self._to_engine(buf))
         return False
+
+    def _expired(self):
+        import time
+        return self._deadline is not None and time.perf_counter() >= self._deadline
 
     def _slice(self, stats, epoch):
         """bursts of iterations until the slice is used up, the pool is dry, or a neighbour waits at the next
@@ -284,12 +302,16 @@ class ShardedSearch:
                 break
             if self.objective == OBJ_ANY and stats["solutions"] > 0:
                 break
+            if self._expired():
+                if self.page is not None:
+                    self.page.set_timeout()
+                break
             page = self.page
             if page is not None:
                 page.publish(best=stats["best"], found=1 if stats["solutions"] > 0 else 0, pool=stats["pool"])
                 if self.objective in (OBJ_MIN, OBJ_MAX):
                     self.engine.set_best(page.best(self.objective))
-                if page.waiting_at() > epoch or (self.objective == OBJ_ANY and page.any_found()):
+                if page.waiting_at() > epoch or page.timed_out() or (self.objective == OBJ_ANY and page.any_found()):
                     if used < self.slice_iterations:
                         self.early_exchanges += 1
                     break
@@ -299,6 +321,7 @@ class ShardedSearch:
         """-> (local stats dict, global totals dict).  Counters of the common seeding phase are counted once."""
         import time
         t_start = time.perf_counter()
+        self._deadline = None if self.time_limit is None else t_start + self.time_limit
         self._open_page()
         if self.page is not None:
             self.page.publish(want=0, best=INT32_MAX if self.objective == OBJ_MIN else INT32_MIN, found=0, pool=0)
@@ -310,7 +333,9 @@ class ShardedSearch:
         for _ in range(max_slices):
             stats = self._slice(stats, epoch)
             if self.dist is None:
-                if stats["done"]:
+                if self._expired():
+                    self.timed_out = True
+                if stats["done"] or self.timed_out:
                     break
                 continue
             epoch += 1
@@ -338,6 +363,7 @@ class ShardedSearch:
             elif self.objective == OBJ_MAX:
                 self.dist.all_reduce(b, op=self.dist.ReduceOp.MAX)
             totals["best"] = int(b.item())
+        totals["timeout"] = local["timeout"] = bool(self.timed_out)
         if self.page is not None:
             self.page.close()
             self.page = None

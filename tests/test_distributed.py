@@ -55,7 +55,7 @@ def _worker(rank, world, port, text, out_q, options=None):
     local, totals = sh.run(root)
     assert sh.seconds["total"] >= sh.seconds["busy"] > 0 and 0.0 <= sh.idle_fraction() <= 1.0
     out_q.put((rank, local["nodes"], local["solutions"], totals["nodes"], totals["solutions"], totals["best"],
-               sh.states_moved, bool(sh.seeded_alike), sh.early_exchanges))
+               sh.states_moved, bool(sh.seeded_alike), sh.early_exchanges, bool(totals["timeout"])))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -148,3 +148,15 @@ def test_lanes_in_one_process():
     lanes = [_oracle_engine(text)[1] for _ in range(2)]
     tot = LaneSearch(lanes, om.view.objective, slice_iterations=8, seed_states_per_lane=4, low_water=4).run(root)
     assert tot["done"] == 1 and tot["best"] == 22
+
+
+def test_time_limit_stops_every_rank_with_partial_results():
+    """the reference's -t (shared()->timeout, csolve.c:190-203,408): after the time limit every rank stops in the same
+    exchange, the totals say so and hold what was found so far; without a limit the flag stays false"""
+    from csolve_amd import problems
+    res = _run(3, problems.queens(10, "ALL"), dict(time_limit=0.03, slice_iterations=4, poll_iterations=1))
+    assert all(r[9] for r in res), "a rank did not see the timeout"
+    assert len({(r[3], r[4]) for r in res}) == 1, "the ranks disagree on the totals"
+    assert 0 < res[0][3] and res[0][4] < 724, res[0]  # queens-10 has 724 solutions: the search was cut short
+    full = _run(2, problems.queens(6, "ALL"))
+    assert not any(r[9] for r in full) and full[0][4] == 4

@@ -953,10 +953,10 @@ static unsigned *ticket_slot(csgpu_model *m, void *stream) {
 static int launch_shave(const csgpu_model *m, const csgpu_val *d_states_in, const csgpu_node *d_nodes,
                         csgpu_val *d_states_out, csgpu_result *d_results, int64_t batch, const uint64_t *d_batch,
                         void *stream) {
-  /* two nodes per chunk; a batch smaller than the machine is spread one node per wave */
-  int csz = CS_SHAVE_CHUNK;
+  /* four or two nodes per chunk; fewer while that would leave a wave with less than four chunks */
+  int csz = m->host->n_vars <= CS_WAVE ? 2 * CS_SHAVE_CHUNK : CS_SHAVE_CHUNK; /* four per ticket when a node is one register per lane */
   const int64_t machine_waves = (int64_t)m->n_cus * 32;
-  if ((batch + csz - 1) / csz < machine_waves) csz = 1;
+  while (csz > 1 && (batch + csz - 1) / csz < 4 * machine_waves) csz >>= 1; /* every wave gets several chunks */
   const int64_t chunks = (batch + csz - 1) / csz;
   size_t wgs = (160u * 1024u) / m->dense_bytes;
   if (wgs > (size_t)(32 / m->dense_waves)) wgs = (size_t)(32 / m->dense_waves);

@@ -105,12 +105,12 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_shave(
     int n, const E *__restrict__ tab_g, int slots, int dmin, const int *__restrict__ root_lo,
     const int *__restrict__ sym_off, const cs_val *__restrict__ states_in, const cs_node_in *__restrict__ nodes,
     cs_val *__restrict__ states_out, cs_node_out *__restrict__ results, long long batch,
-    const unsigned long long *__restrict__ batch_dev, int csz /* 1 or 2 nodes per chunk */, unsigned *tickets,
+    const unsigned long long *__restrict__ batch_dev, int csz /* nodes per chunk: 1 .. D */, unsigned *tickets,
     int4 *__restrict__ trace, unsigned *__restrict__ trace_n, unsigned trace_cap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
   typedef unsigned long long u64;
   constexpr int W = CS_WAVE * R; /* columns of the table */
-  constexpr int D = CS_SHAVE_CHUNK;
+  constexpr int D = R == 1 && !TRACE ? 2 * CS_SHAVE_CHUNK : CS_SHAVE_CHUNK; /* 64-variable models: four nodes per ticket (with two registers per lane the rows in flight spill) */
   if (batch_dev != nullptr && (long long)*batch_dev < batch) batch = (long long)*batch_dev;
   /* the ABI's batches stay below 2^31 nodes: node numbers are 32-bit scalars from here on (the scalar unit, which
    * bounds this kernel -- 119 scalar against 105 vector instructions per node on queens-64,
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_shave(
       auto trace_lanes = [&](u64 mask, int r2, int kind, int value, int cause) {
         if (mask == 0ull) return;
         const unsigned at = tcount + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-        if (((mask >> lane) & 1ull) != 0ull && at < trace_cap)
+        if (__builtin_amdgcn_inverse_ballot_w64(mask) && at < trace_cap) /* (no 64-bit shift by a lane number: tools/k4_fault_repro.md) */
           trace[at] = make_int4(lane + r2 * CS_WAVE, kind, value + b0[r2], cause);
         tcount += (unsigned)__builtin_popcountll(mask);
       };

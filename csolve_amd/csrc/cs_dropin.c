@@ -262,6 +262,29 @@ static double now_s(void) {
 }
 void csolve_dropin_seconds(double out[3]) { memcpy(out, g_seconds, sizeof g_seconds); }
 
+/* per-call device times of propagate_clauses (the first 2^20 calls): where a search's time goes call by call */
+#define CS_CALL_TIMES (1 << 20)
+static float *g_call_us;
+static size_t g_call_n;
+static void note_call(double seconds) {
+  if (g_call_us == NULL) g_call_us = (float *)malloc((size_t)CS_CALL_TIMES * sizeof(float));
+  if (g_call_us != NULL && g_call_n < CS_CALL_TIMES) g_call_us[g_call_n++] = (float)(seconds * 1e6);
+}
+static int cmp_float(const void *a, const void *b) { return (*(const float *)a > *(const float *)b) - (*(const float *)a < *(const float *)b); }
+/* out = { first call, median, 90th percentile, maximum } in microseconds (0 without calls) */
+void csolve_dropin_call_times(double out[4]) {
+  out[0] = out[1] = out[2] = out[3] = 0.0;
+  if (g_call_n == 0) return;
+  out[0] = g_call_us[0];
+  float *sorted = (float *)malloc(g_call_n * sizeof(float));
+  memcpy(sorted, g_call_us, g_call_n * sizeof(float));
+  qsort(sorted, g_call_n, sizeof(float), cmp_float);
+  out[1] = sorted[g_call_n / 2];
+  out[2] = sorted[(g_call_n * 9) / 10];
+  out[3] = sorted[g_call_n - 1];
+  free(sorted);
+}
+
 static void fatal_gpu(const char *what) { print_fatal("%s: %s", what, csgpu_last_error()); }
 
 /* Values of expression nodes, valid while no domain changes: the driver's normalize() (normalize.c:67-75,
@@ -624,6 +647,7 @@ prop_result_t propagate_clauses(const struct clause_list_t *clauses) {
   const double t0 = now_s(), dev0 = g_seconds[1];
   const prop_result_t r = propagate_clauses_timed(clauses);
   g_seconds[2] += (now_s() - t0) - (g_seconds[1] - dev0);
+  note_call(g_seconds[1] - dev0);
   return r;
 }
 

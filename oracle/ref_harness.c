@@ -572,13 +572,17 @@ int main(int argc, char **argv) {
       extern void csolve_dropin_seconds(double out[3]);
       double sec[3];
       csolve_dropin_seconds(sec);
+      extern void csolve_dropin_call_times(double out[4]);
+      double ct[4];
+      csolve_dropin_call_times(ct);
       extern void csolve_dropin_learning_counters(uint64_t out[2]);
       uint64_t lc[2];
       csolve_dropin_learning_counters(lc);
       printf("@DROPIN {\"propagate_clauses\": %lu, \"propagate\": %lu, \"eval\": %lu, \"single_op\": %lu, "
              "\"sibling_batches\": %lu, \"served_from_batch\": %lu, \"conflicts_offered\": %lu, \"reattached\": %lu, "
-             "\"attach_seconds\": %.6f, \"device_call_seconds\": %.6f, \"shim_host_seconds\": %.6f}\n", k[0], k[1], k[2],
-             k[3], sb[0], sb[1], lc[0], lc[1], sec[0], sec[1], sec[2]);
+             "\"attach_seconds\": %.6f, \"device_call_seconds\": %.6f, \"shim_host_seconds\": %.6f, "
+             "\"call_us_first\": %.1f, \"call_us_median\": %.1f, \"call_us_p90\": %.1f, \"call_us_max\": %.1f}\n", k[0], k[1], k[2],
+             k[3], sb[0], sb[1], lc[0], lc[1], sec[0], sec[1], sec[2], ct[0], ct[1], ct[2], ct[3]);
     }
 #endif
     printf("@STATS {\"feasible_root\": %s, \"calls\": %lu, \"cuts\": %lu, \"props\": %lu, \"confl\": %lu, "

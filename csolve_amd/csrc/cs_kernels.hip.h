@@ -755,6 +755,7 @@ __global__ __launch_bounds__(CS_BLOCK) void cs_propagate_clause_rounds(cs_tables
  *   - revisions are counted per scan (scalar), not per lane.
  */
 #define CS_CHUNK 16 /* nodes a wave takes at a time: their records sit in lanes 0..15 */
+__device__ __forceinline__ int cs_wave_sum(int x); /* below */
 
 /* ADJ_LDS = false: the adjacency stays in device memory (it is a few tens of KB that every workgroup reads: L2-resident)
  * and LDS holds the per-wave slices only -- for models whose lists would leave room for a handful of waves (a 25x25
@@ -946,13 +947,28 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_lds(cs
       int open_vars = 0;
       if (!failed) {
         cs_val *dst = states_out + (size_t)(base + j) * n;
-        for (int v = lane; v < n; v += CS_WAVE) {
+        /* R strides straight through (all LDS reads in flight, then the stores), the tail of a larger state after them;
+         * open variables are counted per lane and summed once */
+        int open_l = 0;
+        cs_val dd[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          const int v = lane + r * CS_WAVE;
+          dd[r] = v < n ? dom[v] : cs_value(0);
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          const int v = lane + r * CS_WAVE;
+          if (v < n) dst[v] = dd[r];
+          open_l += dd[r].lo != dd[r].hi ? 1 : 0;
+        }
+        for (int v = lane + R * CS_WAVE; v < n; v += CS_WAVE) {
           const cs_val d = dom[v];
           dst[v] = d;
-          open_vars += __popcll(__ballot(d.lo != d.hi));
+          open_l += d.lo != d.hi ? 1 : 0;
         }
+        open_vars = cs_wave_sum(open_l);
       }
-      open_vars = __builtin_amdgcn_readfirstlane(open_vars); /* lanes >= n_vars never ran the loop */
       if (lane == j) { /* lane j keeps node j's result; one coalesced store per chunk */
         my_result.status = failed ? -1 : open_vars;
         my_result.props = props;

@@ -574,19 +574,28 @@ static const void *ne_shave_kernel(int width, int n_vars, int slots, int full) {
 #undef CS_PICK_F
 }
 
-/* its tracing variant for single nodes (run-time slot count, guarded lanes: six instantiations in all) */
-static const void *ne_shave_trace_kernel(int width, int n_vars) {
+/* its tracing variant for single nodes (guarded lanes; the slot count a constant when 1 or 3: with the run-time loop
+ * the six LDS reads of a row operation are waited for one by one, which is the latency of a single wavefront) */
+static const void *ne_shave_trace_kernel(int width, int n_vars, int slots) {
   const int chunks = (n_vars + CS_WAVE - 1) / CS_WAVE;
   const int r = chunks <= 1 ? 1 : (chunks <= 2 ? 2 : 4);
+  const int sl = slots == 1 ? 1 : (slots == 3 ? 3 : 0);
+#define CS_PICK_S(E, RR)                                                                           \
+  switch (sl) {                                                                                    \
+  case 1: return (const void *)cs_propagate_ne_shave<E, RR, 1, false, true>;                        \
+  case 3: return (const void *)cs_propagate_ne_shave<E, RR, 3, false, true>;                        \
+  default: return (const void *)cs_propagate_ne_shave<E, RR, 0, false, true>;                       \
+  }
 #define CS_PICK(E)                                                                                 \
   switch (r) {                                                                                     \
-  case 1: return (const void *)cs_propagate_ne_shave<E, 1, 0, false, true>;                         \
-  case 2: return (const void *)cs_propagate_ne_shave<E, 2, 0, false, true>;                         \
-  default: return (const void *)cs_propagate_ne_shave<E, 4, 0, false, true>;                        \
+  case 1: CS_PICK_S(E, 1)                                                                          \
+  case 2: CS_PICK_S(E, 2)                                                                          \
+  default: CS_PICK_S(E, 4)                                                                         \
   }
   if (width == 1) { CS_PICK(unsigned char) }
   CS_PICK(unsigned short)
 #undef CS_PICK
+#undef CS_PICK_S
 }
 
 /* kernel 5: kernel 4 for small models, 64 / n_vars (2 or 4) nodes per wave; needs the 8-bit dense table (its
@@ -794,7 +803,10 @@ extern "C" int csgpu_model_finalize(csgpu_model *m) {
               return rc;
           for (int full = 0; full < 2; full++)
             if ((rc = lds_limit(bytes, ne_shave_kernel(m->img->dense_width, h->n_vars, m->img->dense_slots, full)))) return rc;
-          if ((rc = lds_limit(bytes, ne_shave_trace_kernel(m->img->dense_width, h->n_vars)))) return rc;
+          if (((bytes + 15) & ~(size_t)15) + CS_SHAVE_TRACE_LDS * 16 <= 160u * 1024u &&
+              (rc = lds_limit(((bytes + 15) & ~(size_t)15) + CS_SHAVE_TRACE_LDS * 16,
+                              ne_shave_trace_kernel(m->img->dense_width, h->n_vars, m->img->dense_slots))))
+            return rc;
           HIP_TRY(hipMalloc((void **)&m->d_tickets, (size_t)CS_TICKET_SLOTS * CS_TICKET_SLOT_WORDS * sizeof(unsigned)));
           HIP_TRY(hipMemset(m->d_tickets, 0, (size_t)CS_TICKET_SLOTS * CS_TICKET_SLOT_WORDS * sizeof(unsigned)));
           m->ticket_slots = CS_TICKET_SLOTS;
@@ -1446,8 +1458,10 @@ extern "C" int csgpu_propagate_one_causes(const csgpu_model *cm, const csgpu_val
   csgpu_result *d_res = (csgpu_result *)m->d_one_res;
   void *args[] = { &n, &tab_d, &slots, &dmin_d, &root_lo_d, &sym_off, &d_in, &d_node, &d_out, &d_res,
                    &nb_d, &d_batch, &csz, &tickets, &d_trace, &d_trace_n, &ucap };
-  HIP_TRY(hipLaunchKernel(ne_shave_trace_kernel(m->img->dense_width, n), dim3(1), dim3((unsigned)(m->dense_waves * CS_WAVE)),
-                          args, m->dense_bytes, (hipStream_t)NULL));
+  const size_t lds_trace = ((m->dense_bytes + 15) & ~(size_t)15) + CS_SHAVE_TRACE_LDS * 16;
+  if (lds_trace > 160u * 1024u) return set_err(CSGPU_E_LIMIT, "no room in LDS for the trail next to the pair table");
+  HIP_TRY(hipLaunchKernel(ne_shave_trace_kernel(m->img->dense_width, n, slots), dim3(1), dim3((unsigned)(m->dense_waves * CS_WAVE)),
+                          args, lds_trace, (hipStream_t)NULL));
   { const int rcw = wait_null_stream(); if (rcw != CSGPU_OK) return rcw; }
   memcpy(result, m->h_one + part + 64, sizeof *result);
   if (result->status >= 0) memcpy(state_out, m->h_one + part + 128, nbytes);

@@ -266,9 +266,15 @@ void csolve_dropin_seconds(double out[3]) { memcpy(out, g_seconds, sizeof g_seco
 #define CS_CALL_TIMES (1 << 20)
 static float *g_call_us;
 static size_t g_call_n;
+static csgpu_result g_last_res; /* the device's record of the call being timed */
+static struct { float us; csgpu_result res; } g_slowest[8];
 static void note_call(double seconds) {
   if (g_call_us == NULL) g_call_us = (float *)malloc((size_t)CS_CALL_TIMES * sizeof(float));
   if (g_call_us != NULL && g_call_n < CS_CALL_TIMES) g_call_us[g_call_n++] = (float)(seconds * 1e6);
+  int at = 0;
+  for (int i = 1; i < 8; i++)
+    if (g_slowest[i].us < g_slowest[at].us) at = i;
+  if ((float)(seconds * 1e6) > g_slowest[at].us) { g_slowest[at].us = (float)(seconds * 1e6); g_slowest[at].res = g_last_res; }
 }
 static int cmp_float(const void *a, const void *b) { return (*(const float *)a > *(const float *)b) - (*(const float *)a < *(const float *)b); }
 /* out = { first call, median, 90th percentile, maximum } in microseconds (0 without calls) */
@@ -283,6 +289,10 @@ void csolve_dropin_call_times(double out[4]) {
   out[2] = sorted[(g_call_n * 9) / 10];
   out[3] = sorted[g_call_n - 1];
   free(sorted);
+  if (getenv("CSOLVE_DROPIN_SLOW") != NULL) /* what the slowest calls were: status, PROPS, revisions, rounds / failing variable */
+    for (int i = 0; i < 8; i++)
+      fprintf(stderr, "[dropin] slow call: %.1f us, status %d, props %d, revisions %d, rounds %d\n", g_slowest[i].us,
+              g_slowest[i].res.status, g_slowest[i].res.props, g_slowest[i].res.revisions, g_slowest[i].res.rounds);
 }
 
 static void fatal_gpu(const char *what) { print_fatal("%s: %s", what, csgpu_last_error()); }
@@ -318,6 +328,48 @@ void csolve_dropin_detach(void) {
   g_size = 0;
 }
 
+/* The root state: the variables' domains when the last propagate(root, limit) returned (parser.y:64-68 calls it
+ * before and after normalize(); nothing narrows a domain between that and solve()).  A lazy attach happens inside the
+ * driver's first propagate_clauses, when the branching variable is already bound: the model is built on these
+ * domains all the same, so that it is a ROOT model (entailed clauses dropped, forbidden-set and interval-shaving
+ * kernels eligible) -- without them a queens search ran on the general kernel, ten times slower per heavy node. */
+static pmap g_snap;              /* terminal -> index into g_snap_val */
+static struct val_t *g_snap_val;
+static size_t g_snap_n, g_snap_cap;
+
+static void snapshot_terms(const struct constr_t *c, pmap *seen) {
+  if (pmap_get(seen, c) >= 0) return;
+  pmap_put(seen, c, 1);
+  const int op = op_of(c);
+  if (op < 0) {
+    /* keyed by the terminal: the root phase runs before env_generate has given the variables their env_t
+     * (parser.y:64-80), and env_t.val points at this very terminal afterwards */
+    if (g_snap_n == g_snap_cap) {
+      g_snap_cap = g_snap_cap ? g_snap_cap * 2 : 1024;
+      g_snap_val = (struct val_t *)realloc(g_snap_val, g_snap_cap * sizeof *g_snap_val);
+    }
+    g_snap_val[g_snap_n] = c->constr.term.val;
+    pmap_put(&g_snap, c, (int32_t)g_snap_n++);
+  } else if (op == CS_OP_WAND) {
+    for (size_t i = 0; i < c->constr.wand.length; i++) snapshot_terms(c->constr.wand.elems[i].constr, seen);
+  } else if (op == CS_OP_CONFL) {
+    for (size_t i = 0; i < c->constr.confl.length; i++) snapshot_terms(c->constr.confl.elems[i].var, seen);
+  } else {
+    snapshot_terms(c->constr.expr.l, seen);
+    if (c->constr.expr.r != NULL) snapshot_terms(c->constr.expr.r, seen);
+  }
+}
+
+static void snapshot_root(const struct constr_t *root) {
+  if (g_snap.key != NULL) pmap_free(&g_snap);
+  pmap_init(&g_snap, 1 << 12);
+  g_snap_n = 0;
+  pmap seen;
+  pmap_init(&seen, 1 << 12);
+  snapshot_terms(root, &seen);
+  pmap_free(&seen);
+}
+
 static int attach(struct env_t *env, size_t size, struct constr_t *root, int at_root) {
   TRACE("[dropin] attach size=%zu at_root=%d\n", size, at_root);
   const double t_attach = now_s();
@@ -332,8 +384,14 @@ static int attach(struct env_t *env, size_t size, struct constr_t *root, int at_
   pmap clause_ids;
   pmap_init(&clause_ids, 1 << 12);
   f.clause_ids = &clause_ids;
+  int snapped = !at_root && g_snap.key != NULL;
   for (size_t i = 0; i < size; i++) {
     struct val_t v = env[i].val->constr.term.val;
+    if (!at_root && g_snap.key != NULL) {
+      const int32_t k = pmap_get(&g_snap, env[i].val);
+      if (k >= 0) v = g_snap_val[k];
+      else if (env[i].binds != NULL) snapped = 0; /* a variable outside the root tree that has been bound: not the root state */
+    }
     int32_t id = cs_model_add_var(f.m, env[i].key ? env[i].key : "?", cs_interval(v.lo, v.hi));
     f.m->prio[id] = env[i].prio;
     /* the variable's own terminal maps to its VAR node */
@@ -390,14 +448,15 @@ static int attach(struct env_t *env, size_t size, struct constr_t *root, int at_
   pmap_free(&clause_ids);
   flat_done(&f);
 
-  if (csgpu_model_from_host(f.m, 1, at_root, &g_model) != CSGPU_OK) fatal_gpu("attach");
+  if (csgpu_model_from_host(f.m, 1, at_root || snapped, &g_model) != CSGPU_OK) fatal_gpu("attach");
   if (csgpu_model_finalize(g_model) != CSGPU_OK) fatal_gpu("attach");
   g_env = env;
   g_size = size;
   g_root = root;
   g_state = (csgpu_val *)malloc((size ? size : 1) * sizeof *g_state);
   g_out = (csgpu_val *)malloc((size ? size : 1) * sizeof *g_out);
-  TRACE("[dropin] attached\n");
+  TRACE("[dropin] attached: root model %d (snapshot of %zu variables), interval-shaving kernel %s\n", at_root || snapped, g_snap_n,
+        csgpu_model_qualifies(g_model, 7) == 1 ? "eligible" : "not eligible");
   g_seconds[0] += now_s() - t_attach;
   return 0;
 }
@@ -730,15 +789,20 @@ static prop_result_t propagate_clauses_timed(const struct clause_list_t *clauses
   csgpu_result res;
   TRACE("[dropin] propagate_clauses var=%d [%d,%d]\n", node.var, node.lo, node.hi);
   const double td = now_s();
-  if (!learning() && chain_mode() && csgpu_model_qualifies(g_model, 7) == 1) {
+  static int no_causes; /* the model's pair table leaves no room for the trail in LDS: the clause trail instead */
+  if (!learning() && chain_mode() && !no_causes && csgpu_model_qualifies(g_model, 7) == 1) {
     /* pure != network: kernel 7's trail, at the latency of the untraced call */
     if (g_trail == NULL) g_trail = (int32_t *)malloc((size_t)CS_TRAIL_CAP * 4 * sizeof(int32_t));
     int32_t count = 0;
-    if (csgpu_propagate_one_causes(g_model, g_state, node, g_out, &res, g_trail, CS_TRAIL_CAP, &count) != CSGPU_OK)
-      fatal_gpu("propagate_clauses");
-    g_seconds[1] += now_s() - td;
-    TRACE("[dropin]   -> status %d props %d, %d cause records\n", res.status, res.props, count);
-    return deliver_causes(var, &res, g_out, count);
+    const int rc = csgpu_propagate_one_causes(g_model, g_state, node, g_out, &res, g_trail, CS_TRAIL_CAP, &count);
+    if (rc == CSGPU_OK) {
+      g_seconds[1] += now_s() - td;
+      TRACE("[dropin]   -> status %d props %d, %d cause records\n", res.status, res.props, count);
+      g_last_res = res;
+      return deliver_causes(var, &res, g_out, count);
+    }
+    if (rc != CSGPU_E_LIMIT) fatal_gpu("propagate_clauses");
+    no_causes = 1;
   }
   if (learning() || chain_mode()) {
     if (g_trail == NULL) g_trail = (int32_t *)malloc((size_t)CS_TRAIL_CAP * 4 * sizeof(int32_t));
@@ -747,11 +811,13 @@ static prop_result_t propagate_clauses_timed(const struct clause_list_t *clauses
       fatal_gpu("propagate_clauses");
     g_seconds[1] += now_s() - td;
     TRACE("[dropin]   -> status %d props %d, %d trail records\n", res.status, res.props, count);
+    g_last_res = res;
     return deliver_traced(var, &res, g_out, count);
   }
   if (csgpu_propagate_one(g_model, g_state, node, g_out, &res) != CSGPU_OK) fatal_gpu("propagate_clauses");
   g_seconds[1] += now_s() - td;
   TRACE("[dropin]   -> status %d props %d rounds %d\n", res.status, res.props, res.rounds);
+  g_last_res = res;
   return deliver(var, &res, g_out);
 }
 
@@ -814,7 +880,9 @@ prop_result_t propagate(struct constr_t *constr, size_t limit) {
   g_root = constr;
   g_calls[1]++;
   struct val_t t = { 1, 1 };
-  return propagate_tree(constr, t, NULL, 0, limit > (size_t)0x7ffffff0 ? -1 : (int64_t)limit);
+  const prop_result_t r = propagate_tree(constr, t, NULL, 0, limit > (size_t)0x7ffffff0 ? -1 : (int64_t)limit);
+  if (r != PROP_ERROR) snapshot_root(constr);
+  return r;
 }
 
 /* ---- eval ----------------------------------------------------------------------------------------- */

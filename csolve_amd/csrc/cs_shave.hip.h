@@ -90,6 +90,7 @@ __device__ __forceinline__ int cs_writelane_at(int lane, int v, int x) {
   }
 }
 
+#define CS_SHAVE_TRACE_LDS 2048u /* trace records kept in LDS (32 KB) by the tracing variant */
 #define CS_SHAVE_CHUNK 2        /* nodes per chunk = parent rows in flight per wave */
 #define CS_SHAVE_SHARDS 64      /* ticket counters per launch at most */
 #define CS_SHAVE_TICKET_STRIDE 16 /* unsigned words between two counters: one 64-byte line each */
@@ -130,6 +131,8 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_shave(
   if ((int)(blockIdx.x / nsh) * waves_per_block >= count_x) return; /* no chunk for any wave of this workgroup */
   if (SL != 0) slots = SL;
   const E *s_tab = (const E *)cs_lds;
+  /* TRACE: the records of the node are collected behind the table */
+  int4 *s_trace = (int4 *)(cs_lds + ((((size_t)n * slots * W * sizeof(E)) + 15) & ~(size_t)15));
   {
     const int vecs = (int)(((size_t)n * slots * W * sizeof(E)) / 16);
     const uint4 *src = (const uint4 *)tab_g;
@@ -267,8 +270,10 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_shave(
       auto trace_lanes = [&](u64 mask, int r2, int kind, int value, int cause) {
         if (mask == 0ull) return;
         const unsigned at = tcount + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-        if (__builtin_amdgcn_inverse_ballot_w64(mask) && at < trace_cap) /* (no 64-bit shift by a lane number: tools/k4_fault_repro.md) */
-          trace[at] = make_int4(lane + r2 * CS_WAVE, kind, value + b0[r2], cause);
+        /* into LDS: a store to the caller's (host-mapped) buffer would be waited for before the registers are reused,
+         * a PCIe round trip per row operation (measured: 3.4 us per operation, 1 ms for a cascade of 300) */
+        if (__builtin_amdgcn_inverse_ballot_w64(mask) && at < CS_SHAVE_TRACE_LDS) /* (no 64-bit shift by a lane number: tools/k4_fault_repro.md) */
+          s_trace[at] = make_int4(lane + r2 * CS_WAVE, kind, value + b0[r2], cause);
         tcount += (unsigned)__builtin_popcountll(mask);
       };
       int rounds = 0, revisions = 0;
@@ -477,7 +482,11 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_shave(
       };
       const int fail_var = fixpoint();
       const int failed = fail_var >= 0;
-      if (TRACE && lane == 0) *trace_n = tcount;
+      if (TRACE) { /* the records leave LDS in one coalesced burst; a count beyond the buffer tells the caller they are incomplete */
+        const unsigned keep = tcount < CS_SHAVE_TRACE_LDS ? tcount : CS_SHAVE_TRACE_LDS;
+        for (unsigned i = lane; i < keep && i < trace_cap; i += CS_WAVE) trace[i] = s_trace[i];
+        if (lane == 0) *trace_n = tcount <= CS_SHAVE_TRACE_LDS ? tcount : (tcount > trace_cap ? tcount : trace_cap + 1u);
+      }
       if (rounds != 0) __builtin_amdgcn_s_setprio(0);
 
       int open_vars = 0, shaved = 0;

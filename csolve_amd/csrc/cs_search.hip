@@ -853,11 +853,19 @@ __global__ __launch_bounds__(SB) void cs_accept(const cs_val *__restrict__ compl
     for (int v = 0; v < n; v++) solutions[v] = complete[(size_t)(list != nullptr ? list[first] : first) * n + v].lo;
     return;
   }
+  /* the count goes through LDS: one device atomic per workgroup (a word takes about 88 atomics per microsecond, and an
+   * ALL iteration of queens-16 accepts 80,000 children: one atomic per wave was 14 of the kernel's 17 us) */
+  __shared__ unsigned s_accepted;
+  if (threadIdx.x == 0) s_accepted = 0u;
+  __syncthreads();
   const bool ok = i < count && (truth == nullptr || truth[i] == 1); /* truth == NULL: every complete child is a solution */
   const size_t row = ok ? (size_t)(list != nullptr ? list[i] : i) * n : 0;
   const unsigned long long mask = __ballot(ok);
+  const int accepted = __popcll(mask), leader = mask != 0ull ? __builtin_ctzll(mask) : 0;
+  if (mask != 0ull && lane == leader) atomicAdd(&s_accepted, (unsigned)accepted);
+  __syncthreads();
+  if (threadIdx.x == 0 && s_accepted != 0u) atomicAdd(&counters[C_SOLUTIONS], (unsigned long long)s_accepted);
   if (mask == 0ull) return;
-  const int accepted = __popcll(mask), leader = __builtin_ctzll(mask);
   if (objective == CS_OBJ_MIN || objective == CS_OBJ_MAX) {
     int val = objective == CS_OBJ_MIN ? 0x7fffffff : (int)0x80000000;
     if (ok) val = objective == CS_OBJ_MIN ? complete[row + obj_var].lo : complete[row + obj_var].hi;
@@ -872,7 +880,6 @@ __global__ __launch_bounds__(SB) void cs_accept(const cs_val *__restrict__ compl
   }
   long long slot0 = max_solutions;
   if (lane == leader) {
-    atomicAdd(&counters[C_SOLUTIONS], (unsigned long long)accepted);
     /* which solutions are kept may vary; their count does not.  Once the store is full nobody asks for a slot */
     if (counters[C_STORED] < (unsigned long long)max_solutions)
       slot0 = (long long)atomicAdd(&counters[C_STORED], (unsigned long long)accepted);

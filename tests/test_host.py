@@ -293,3 +293,40 @@ def test_luby_and_value_order_against_the_reference_unit_vectors():
     walk = [L.csgpu_step_val(b, i, 0) for i in range(b.hi - b.lo + 1)]
     assert walk[:4] == [3, 17, 4, 16] and sorted(walk) == list(range(3, 18))
     assert [L.csgpu_step_val(b, i, 1) for i in range(4)] == [17, 3, 16, 4]
+
+
+# ---- the grammar, pinned independently of the front end's self-consistency --------------------------------------
+
+def _sexpr(m, i):
+    v = m.view
+    op, a, b = v.nodes[3 * i], v.nodes[3 * i + 1], v.nodes[3 * i + 2]
+    name = [k for k, x in OPS.items() if x == op][0]
+    if name == "VAR":
+        return m.names()[a]
+    if name == "CONST":
+        return str(a) if a == b else f"[{a},{b}]"
+    if name == "WAND":
+        return "(WAND " + " ".join(_sexpr(m, v.kids[a + k]) for k in range(b)) + ")"
+    return "(" + name + " " + _sexpr(m, a) + ("" if b < 0 else " " + _sexpr(m, b)) + ")"
+
+
+@pytest.mark.parametrize("case", json.load(open(golden("grammar_expectations.json")))["cases"],
+                         ids=lambda c: c["ref"].split(" ", 1)[0])
+def test_front_end_builds_the_trees_the_reference_grammar_prescribes(case):
+    """cs_frontend.c against expectations derived by hand from the ACTIONS of the reference's grammar (src/parser.y, read
+    as text): operator precedence and associativity, the desugaring of > <= >= != and binary minus, all_different, the
+    objective element and the <obj> variable, one terminal per identifier.  (The compiled reference in oracle/_ref is
+    fed by this same front end, so its dumps cannot pin the grammar; these can.)"""
+    m = OModel.parse(case["text"], weights_on=False)
+    v = m.view
+    op, off, count = v.nodes[3 * v.root], v.nodes[3 * v.root + 1], v.nodes[3 * v.root + 2]
+    assert op == OPS["WAND"]
+    got = [_sexpr(m, v.kids[off + k]) for k in range(count)]
+    assert got == case["elems"], (case["ref"], got)
+    if "objective" in case:
+        assert v.objective == {"ANY": 0, "ALL": 1, "MIN": 2, "MAX": 3}[case["objective"]]
+        assert (v.obj_var >= 0) == (case["objective"] in ("MIN", "MAX"))
+    if "vars" in case:
+        assert m.names() == case["vars"]
+    for name, dom in case.get("domains", {}).items():
+        assert m.domains()[m.names().index(name)].tolist() == dom

@@ -330,3 +330,12 @@ def test_front_end_builds_the_trees_the_reference_grammar_prescribes(case):
         assert m.names() == case["vars"]
     for name, dom in case.get("domains", {}).items():
         assert m.domains()[m.names().index(name)].tolist() == dom
+
+
+def test_front_end_weights_as_the_reference_grammar_prescribes():
+    """the initial ordering weights (env_t.prio) of parser.y's relational / equality actions, derived by hand"""
+    w = json.load(open(golden("grammar_expectations.json")))["weights"]
+    for case in w["cases"]:
+        m = OModel.parse(case["text"], weights_on=True)
+        got = dict(zip(m.names(), [m.view.prio[i] for i in range(m.n_vars)]))
+        assert got == case["prio"], (case["text"], got)

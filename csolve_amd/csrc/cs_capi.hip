@@ -1467,7 +1467,9 @@ extern "C" int csgpu_propagate_one_causes(const csgpu_model *cm, const csgpu_val
   if (result->status >= 0) memcpy(state_out, m->h_one + part + 128, nbytes);
   const unsigned made = *m->h_trace_n;
   *count = (int32_t)made;
-  memcpy(trace, m->h_trace, (size_t)(made < (unsigned)cap ? made : (unsigned)cap) * 16);
+  unsigned kept = made < CS_SHAVE_TRACE_LDS ? made : CS_SHAVE_TRACE_LDS; /* what the kernel's LDS buffer holds */
+  if (kept > (unsigned)cap) kept = (unsigned)cap;
+  memcpy(trace, m->h_trace, (size_t)kept * 16);
   return CSGPU_OK;
 }
 

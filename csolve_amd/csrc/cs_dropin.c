@@ -601,8 +601,9 @@ static prop_result_t deliver_causes(int32_t var, const csgpu_result *res, const 
       }
     return res->props;
   }
-  /* the failure: the first record whose move empties its variable */
-  const int32_t have = count < CS_TRAIL_CAP ? count : CS_TRAIL_CAP;
+  /* the failure: the first record whose move empties its variable (a trail longer than the device keeps -- 2,048
+   * records -- is not walked: the emptied variable alone is bumped then) */
+  const int32_t have = count <= 2048 && count <= CS_TRAIL_CAP ? count : 0;
   int32_t fail_var = -1, fail_at = -1;
   for (int32_t r = 0; r < have && fail_var < 0; r++) {
     const int32_t v = g_trail[4 * r], kind = g_trail[4 * r + 1], bound = g_trail[4 * r + 2];

@@ -482,10 +482,10 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_shave(
       };
       const int fail_var = fixpoint();
       const int failed = fail_var >= 0;
-      if (TRACE) { /* the records leave LDS in one coalesced burst; a count beyond the buffer tells the caller they are incomplete */
+      if (TRACE) { /* the records leave LDS in one coalesced burst; a count beyond CS_SHAVE_TRACE_LDS tells the caller that only that many were kept */
         const unsigned keep = tcount < CS_SHAVE_TRACE_LDS ? tcount : CS_SHAVE_TRACE_LDS;
         for (unsigned i = lane; i < keep && i < trace_cap; i += CS_WAVE) trace[i] = s_trace[i];
-        if (lane == 0) *trace_n = tcount <= CS_SHAVE_TRACE_LDS ? tcount : (tcount > trace_cap ? tcount : trace_cap + 1u);
+        if (lane == 0) *trace_n = tcount;
       }
       if (rounds != 0) __builtin_amdgcn_s_setprio(0);
 

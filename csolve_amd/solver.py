@@ -271,8 +271,8 @@ class Model:
         cnt = C.c_int32()
         check(load_library().csgpu_propagate_one_causes(self._h, state.ctypes.data, Node(var, lo, hi, 0), out.ctypes.data,
                                                         C.byref(res), trace.ctypes.data, cap, C.byref(cnt)))
-        if cnt.value > cap:
-            raise OverflowError(f"{cnt.value} trace records, room for {cap}")
+        if cnt.value > min(cap, 2048):
+            raise OverflowError(f"{cnt.value} trace records, {min(cap, 2048)} kept")
         return res.status, res.props, (out if res.status >= 0 else None), trace[: cnt.value].copy()
 
     def propagate_one_traced(self, state: np.ndarray, var: int, lo: int, hi: int, cap: int = 4096):

@@ -344,7 +344,8 @@ int csgpu_propagate_one_traced(const csgpu_model *m, const csgpu_val *state, csg
 /* The trail of one node of a pure != network with the CAUSE of every bound move as a variable: records
  * {variable, 0 = lower bound raised / 1 = upper bound lowered, new bound, the valued variable whose value forbade the
  * old bound}, in the order the moves were made (one wavefront: replaying them in sequence gives the fixpoint; the
- * first record that empties a domain is the failure).  Runs the interval-only shaving kernel (models that qualify
+ * first record that empties a domain is the failure).  *count = moves made; at most min(cap, 2048) records are kept
+ * (a longer trail is cut off: the caller sees count above that).  Runs the interval-only shaving kernel (models that qualify
  * for kernel 7, CSGPU_E_LIMIT otherwise) -- the latency of csgpu_propagate_one.  What the drop-in needs to bump the
  * variables on the way from the assignment to a failure (propagate_term_recurse, propagate.c:44-54). */
 int csgpu_propagate_one_causes(const csgpu_model *m, const csgpu_val *state, csgpu_node node, csgpu_val *state_out,

@@ -574,21 +574,28 @@ static const void *ne_shave_kernel(int width, int n_vars, int slots, int full) {
 #undef CS_PICK_F
 }
 
-/* its tracing variant for single nodes (run-time slot count, guarded lanes: six instantiations; specialising on the
- * slot count as well was measured on the drop-in's calls and changed nothing) */
+/* its tracing variant for single nodes (guarded lanes; the slot count a constant when 1 or 3: with the run-time loop
+ * the six LDS reads of a row operation are waited for one by one, which is the latency of a single wavefront) */
 static const void *ne_shave_trace_kernel(int width, int n_vars, int slots) {
-  (void)slots;
   const int chunks = (n_vars + CS_WAVE - 1) / CS_WAVE;
   const int r = chunks <= 1 ? 1 : (chunks <= 2 ? 2 : 4);
+  const int sl = slots == 1 ? 1 : (slots == 3 ? 3 : 0);
+#define CS_PICK_S(E, RR)                                                                           \
+  switch (sl) {                                                                                    \
+  case 1: return (const void *)cs_propagate_ne_shave<E, RR, 1, false, true>;                        \
+  case 3: return (const void *)cs_propagate_ne_shave<E, RR, 3, false, true>;                        \
+  default: return (const void *)cs_propagate_ne_shave<E, RR, 0, false, true>;                       \
+  }
 #define CS_PICK(E)                                                                                 \
   switch (r) {                                                                                     \
-  case 1: return (const void *)cs_propagate_ne_shave<E, 1, 0, false, true>;                         \
-  case 2: return (const void *)cs_propagate_ne_shave<E, 2, 0, false, true>;                         \
-  default: return (const void *)cs_propagate_ne_shave<E, 4, 0, false, true>;                        \
+  case 1: CS_PICK_S(E, 1)                                                                          \
+  case 2: CS_PICK_S(E, 2)                                                                          \
+  default: CS_PICK_S(E, 4)                                                                         \
   }
   if (width == 1) { CS_PICK(unsigned char) }
   CS_PICK(unsigned short)
 #undef CS_PICK
+#undef CS_PICK_S
 }
 
 /* kernel 5: kernel 4 for small models, 64 / n_vars (2 or 4) nodes per wave; needs the 8-bit dense table (its

@@ -881,7 +881,7 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_lds(cs
           my_word = lane < nw ? cur[lane] : 0u;
           nonempty = __ballot(my_word != 0u);
         }
-        for (int w = 0; w < nw && !failed; w++) {
+        for (int w = 0; w < nw; w++) {
           unsigned bits;
           if (nw <= CS_WAVE) {
             if (nonempty == 0ull) break;
@@ -898,7 +898,9 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_lds(cs
             const cs_val du = dom[u];
             const int2 range = ADJ_LDS ? s_off2[u] : make_int2(T.adj_off[u], T.adj_off[u + 1]);
             const int ulo = __builtin_amdgcn_readfirstlane(du.lo), uhi = __builtin_amdgcn_readfirstlane(du.hi);
-            if (ulo > uhi) { failed = 1; break; } /* bounds crossed by racing updates */
+            if (ulo > uhi) { fail = 1; continue; } /* bounds crossed by racing updates (the round is finished all the same:
+                                                    * one exit from the loops, not one per variable, keeps the scalar
+                                                    * bookkeeping of the control flow small) */
             const int beg = __builtin_amdgcn_readfirstlane(range.x), end = __builtin_amdgcn_readfirstlane(range.y);
             revisions += end - beg;
             const int is_value = ulo == uhi;
@@ -929,9 +931,9 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_lds(cs
                 }
               }
             }
-            if (__any(fail)) { failed = 1; break; }
           }
         }
+        if (__any(fail)) failed = 1;
         if (failed || !any) break;
         rounds++;
         cs_wave_sync();

@@ -476,6 +476,10 @@ extern "C" int csgpu_model_eval_clauses_host(csgpu_model *m, csgpu_val *vals) {
 static const void *ne_lds_kernel(int width, int n_vars, int adj_global) {
   int r = 1;
   while (r < 16 && r * CS_WAVE < n_vars) r <<= 1;
+  /* 513 to 640 variables (a 25x25 sudoku): ten strides, not sixteen with six of them empty */
+  if (r == 16 && n_vars <= 10 * CS_WAVE && !adj_global)
+    return width == 2 ? (const void *)cs_propagate_ne_lds<unsigned short, 10, 1, true>
+                      : (const void *)cs_propagate_ne_lds<unsigned int, 10, 1, true>;
 #define CS_PICK_U(E, RR) return adj_global ? (const void *)cs_propagate_ne_lds<E, RR, 1, false> : (const void *)cs_propagate_ne_lds<E, RR, 1, true>;
 #define CS_PICK(E)                                                                                 \
   switch (r) {                                                                                     \

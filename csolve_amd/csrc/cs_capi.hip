@@ -1218,6 +1218,7 @@ extern "C" int csgpu_internal_propagate_objdev(const csgpu_model *m, const csgpu
      * with two chunks next to one with one is a launch twice as long as it needs to be) */
     int csz = (int)(batch / (grid * m->lds_waves * 4));
     csz = csz < 1 ? 1 : (csz > CS_CHUNK ? CS_CHUNK : csz);
+    { const char *e = getenv("CSGPU_K2_CSZ"); if (e != NULL && atoi(e) >= 1 && atoi(e) <= CS_CHUNK) csz = atoi(e); } /* measurement override */
     const int64_t chunks = (batch + csz - 1) / csz;
     const int64_t need = (chunks + m->lds_waves - 1) / m->lds_waves;
     if (grid > need) grid = need;

@@ -145,3 +145,21 @@ def test_reference_driver_with_conflict_learning_on_gpu_propagator(n, m, seed, t
         assert stats["calls"] <= off["calls"], (stats["calls"], off["calls"])
     print(f"n={n} m={m}: reference calls {want['calls']} confl {want['confl']}; "
           f"drop-in calls {stats['calls']} confl {stats['confl']}; drop-in -c false calls {off['calls']}")
+
+
+@pytest.mark.skipif(not os.path.exists(BIN), reason="oracle/_ref/csolve_ref_dropin not built (needs the reference tree)")
+def test_a_lazily_attached_model_is_a_root_model(tmp_path):
+    """zero-patch link: the shim attaches inside the driver's first propagate_clauses, when the branching variable is
+    already bound, and still builds the model on the domains the root phase left (kept from the last propagate(root)):
+    the interval-shaving kernel and its cause trail are eligible, and a call takes tens of microseconds"""
+    from csolve_amd import problems
+    path = tmp_path / "queens40.txt"
+    path.write_text(problems.queens(40))
+    p = subprocess.run([BIN, "solve", str(path), "-c", "false"], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, CSOLVE_DROPIN_TRACE="1"))
+    assert p.returncode == 0, p.stderr[-2000:]
+    attached = [ln for ln in p.stderr.splitlines() if "attached:" in ln]
+    assert len(attached) == 1 and "root model 1" in attached[0] and "kernel eligible" in attached[0], attached
+    assert "cause records" in p.stderr and "trail records" not in p.stderr
+    used = json.loads(re.search(r"@DROPIN (\{.*\})", p.stdout).group(1))
+    assert used["call_us_median"] < 200 and used["propagate_clauses"] > 10

@@ -547,8 +547,24 @@ __global__ __launch_bounds__(CS_BLOCK) void cs_propagate_events(cs_tables T, con
     for (;;) {
       cx.mark = nxt;
       int any = 0;
-      for (int w = 0; w < nw && !failed; w++) {
-        unsigned bits = __builtin_amdgcn_readfirstlane(cur[w]);
+      /* the round's changed mask: lane w holds word w (one LDS read for up to 2048 variables), the non-empty words are
+       * walked through a ballot; one failure exit per round, not one per variable */
+      unsigned my_word = 0u;
+      unsigned long long nonempty = 0ull;
+      if (nw <= CS_WAVE) {
+        my_word = lane < nw ? cur[lane] : 0u;
+        nonempty = __ballot(my_word != 0u);
+      }
+      for (int w = 0; w < nw; w++) {
+        unsigned bits;
+        if (nw <= CS_WAVE) {
+          if (nonempty == 0ull) break;
+          w = __builtin_ctzll(nonempty);
+          nonempty &= nonempty - 1ull;
+          bits = __builtin_amdgcn_readlane(my_word, w);
+        } else {
+          bits = __builtin_amdgcn_readfirstlane(cur[w]);
+        }
         any |= bits != 0u;
         while (bits != 0u) {
           const int u = w * 32 + __builtin_ctz(bits);
@@ -573,9 +589,9 @@ __global__ __launch_bounds__(CS_BLOCK) void cs_propagate_events(cs_tables T, con
               cs_tree_revise(T, ~e.x, cx, S);
             }
           }
-          if (__any(cx.fail)) { failed = 1; break; }
         }
       }
+      if (__any(cx.fail)) failed = 1;
       if (failed || !any) break;
       rounds++;
       cs_wave_sync();

@@ -1188,13 +1188,35 @@ __global__ __launch_bounds__(1024, (FW <= 1 && R <= 1 ? 8 : 4)) void cs_propagat
       int rounds = 0, failed = 0, revisions = 0;
       for (;;) {
         /* (1) newly valued variables push their forbidden value into the neighbours' sets */
-        const int words = small ? 1 : (nw + 1) / 2;
+        /* the round's push set: with more than 64 variables lane w holds 32-bit word w of the mask (one LDS read for up
+         * to 2048 variables) and the non-empty words are walked through a ballot */
+        const bool by_lane = !small && nw <= CS_WAVE;
+        unsigned my_word = 0u;
+        u64 nonempty = 0ull;
+        if (by_lane) {
+          my_word = lane < nw ? cur[lane] : 0u;
+          nonempty = __ballot(my_word != 0u);
+        }
+        const int words = small ? 1 : (by_lane ? nw : (nw + 1) / 2);
         for (int w = 0; w < words; w++) {
-          u64 bits = small ? cur64
-                           : ((u64)(unsigned)__builtin_amdgcn_readfirstlane(cur[2 * w]) |
-                              ((u64)(2 * w + 1 < nw ? (unsigned)__builtin_amdgcn_readfirstlane(cur[2 * w + 1]) : 0u) << 32));
+          u64 bits;
+          int ubase;
+          if (small) {
+            bits = cur64;
+            ubase = 0;
+          } else if (by_lane) {
+            if (nonempty == 0ull) break;
+            w = __builtin_ctzll(nonempty);
+            nonempty &= nonempty - 1ull;
+            bits = (u64)(unsigned)__builtin_amdgcn_readlane(my_word, w);
+            ubase = w * 32;
+          } else {
+            bits = (u64)(unsigned)__builtin_amdgcn_readfirstlane(cur[2 * w]) |
+                   ((u64)(2 * w + 1 < nw ? (unsigned)__builtin_amdgcn_readfirstlane(cur[2 * w + 1]) : 0u) << 32);
+            ubase = w * 64;
+          }
           while (bits != 0ull) {
-            const int u = w * 64 + __builtin_ctzll(bits);
+            const int u = ubase + __builtin_ctzll(bits);
             bits &= bits - 1ull;
             const int c = __builtin_amdgcn_readfirstlane(dom[u].lo);
             const int2 range = s_off2[u];

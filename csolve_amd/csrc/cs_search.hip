@@ -886,7 +886,8 @@ __global__ __launch_bounds__(SB) void cs_accept(const cs_val *__restrict__ compl
   }
   slot0 = __shfl(slot0, leader);
   if (ok) {
-    const long long slot = slot0 + __popcll(mask & ((1ull << lane) - 1ull));
+    /* rank among the accepted lanes below this one: mbcnt, not a 64-bit shift by the lane number (tools/k4_fault_repro.md) */
+    const long long slot = slot0 + (long long)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
     if (slot < max_solutions)
       for (int v = 0; v < n; v++) solutions[(size_t)slot * n + v] = complete[row + v].lo;
   }

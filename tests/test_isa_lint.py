@@ -17,6 +17,19 @@ def test_no_64bit_shift_reads_the_last_register_of_its_allocation():
                        stderr=subprocess.STDOUT, text=True, timeout=900)
     assert r.returncode == 0, r.stdout
     assert " 0 with the amount in the last register" in r.stdout, r.stdout
+    # the lint looks at the code objects inside the built library (what ships), not at a separate compilation
+    assert "shipped code objects of csolve_amd/libcsolve_hip.so" in r.stdout, r.stdout
+
+
+def test_the_source_mode_of_the_lint_uses_the_makefiles_flags():
+    """--from-source (no built library) must compile with the Makefile's HIPFLAGS: register allocation depends on them"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_isa_shift64 as lint
+    flags = lint.makefile_hipflags()
+    assert "--offload-arch=gfx950" in flags and "-O3" in flags
+    mk = open(os.path.join(ROOT, "csolve_amd", "csrc", "Makefile")).read()
+    for f in flags:
+        assert f in mk or f == "--offload-arch=gfx950"
 
 
 def test_the_lint_recognises_the_failing_shape(tmp_path):

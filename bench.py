@@ -33,8 +33,74 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+
+def _launch_ranks_if_needed(argv, script=None):
+    """`python bench.py --gpus N` without a launcher: this process starts the N ranks itself -- fresh child
+    processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, the same command line -- relays rank 0's one JSON
+    line and exits non-zero if any rank does.  It runs before torch or the HIP library is imported: the parent never
+    touches a GPU and nothing is re-executed (the reference forks its workers from one process, csolve.c:105-152;
+    HIP state does not survive a fork, so the ranks are separate processes from the start)."""
+    import socket
+    import subprocess
+    n = 1
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            n = int(argv[i + 1])
+        elif a.startswith("--gpus="):
+            n = int(a.split("=", 1)[1])
+    if n <= 1 or "WORLD_SIZE" in os.environ or "-h" in argv or "--help" in argv:
+        return
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CSOLVE_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
+    out0 = None
+    rc = 0
+    pending = set(range(n))
+    deadline_after_failure = None
+    while pending:
+        for r in sorted(pending):
+            p = procs[r]
+            if r == 0 and out0 is None and p.poll() is not None:
+                out0 = p.stdout.read()
+            if p.poll() is not None:
+                pending.discard(r)
+                if p.returncode != 0:
+                    rc = rc or p.returncode or 1
+                    if deadline_after_failure is None:
+                        deadline_after_failure = time.time() + float(os.environ.get("CSOLVE_BENCH_RANK_GRACE", "20"))
+        if pending and deadline_after_failure is not None and time.time() > deadline_after_failure:
+            for r in pending:  # a rank died: the others may wait for it in a collective for ever
+                procs[r].kill()
+        if pending:
+            if 0 in pending and out0 is None:
+                try:  # drain rank 0's pipe so that it never blocks on a full one
+                    out0, _ = procs[0].communicate(timeout=0.2)
+                except subprocess.TimeoutExpired:
+                    pass
+            else:
+                time.sleep(0.05)
+    if out0:
+        sys.stdout.write(out0)
+        sys.stdout.flush()
+    lines = [ln for ln in (out0 or "").splitlines() if ln.startswith("{")]
+    if rc == 0 and len(lines) != 1:
+        print(f"bench: rank 0 printed {len(lines)} JSON lines", file=sys.stderr)
+        rc = 1
+    sys.exit(rc)
+
+
+if __name__ == "__main__":
+    _launch_ranks_if_needed(sys.argv[1:])
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -246,31 +312,26 @@ def cpu_baseline(args, text, model, states_in, nodes, states_out, res_h):
                       f"on one host core; device results re-checked against it bit for bit"}
 
 
-def search_workload(args, rank, world, local, dist):
-    """BASELINE configs[3]-style run: queens-N ALL, the whole search tree sharded over the ranks
-    (csolve_amd/parallel.py: seeding from rank 0, stealing of open states, shared incumbent).
-    Strong scaling: the tree is fixed, every step is one complete search."""
+def run_sharded_search(args, rank, world, dist, text, steps, warmup, time_limit=None, children=0, pool=0, slice_iterations=0,
+                       max_slices=0):
+    """One sharded search (csolve_amd/parallel.py: every-rank seeding, stealing of open states, shared incumbent)
+    run `warmup` + `steps` times; the timed runs sit between two barriers, the time is the maximum over the ranks.
+    -> dict (the same on every rank): totals of the last run, wall seconds per search, per-rank clocks."""
     from csolve_amd.parallel import ShardedSearch
     from csolve_amd.solver import Search
-    text = problems.queens(args.search_queens, args.search_objective)
-    what = f"queens-{args.search_queens} {args.search_objective}"
-    if args.search_schedule:
-        text = problems.schedule(args.search_schedule, 1)
-        what = f"schedule-{args.search_schedule} MIN (examples/schedule.txt style)"
     model = solve_root(text)
     n = model.n_vars
     comm = "cpu" if args.comm == "gloo" else "cuda"
-
-    max_children = args.children or (1 << 23 if n <= 32 else 1 << 19)  # 2^23: a quarter of the iterations of 2^21 (queens-16 ALL 82.7 -> 74.7 ms)
-    eng = Search(model, args.pool or 8 * max_children, max_children)  # buffers are allocated once, outside the timed region
+    max_children = children or (1 << 23 if n <= 32 else 1 << 19)  # 2^23: a quarter of the iterations of 2^21 (queens-16 ALL 82.7 -> 74.7 ms)
+    eng = Search(model, pool or 8 * max_children, max_children)  # buffers are allocated once, outside the timed region
 
     def once():
         eng.reset()
         sh = ShardedSearch(eng, model.objective, n, rank, world, dist, engine_device="cuda", comm_device=comm,
-                           slice_iterations=args.slice or (64 if model.objective == 1 else 256),  # 1 = ALL; a dry rank calls the exchange earlier
+                           slice_iterations=slice_iterations or (64 if model.objective == 1 else 256),  # 1 = ALL; a dry rank calls the exchange earlier
                            seed_states_per_rank=256, low_water=4096, poll_iterations=args.poll,
-                           time_limit=args.time_limit if args.time_limit > 0 else None)
-        local_stats, totals = sh.run(model.root_state(), args.search_slices if args.search_slices > 0 else 1 << 40)
+                           time_limit=time_limit if time_limit else None)
+        local_stats, totals = sh.run(model.root_state(), max_slices if max_slices > 0 else 1 << 40)
         return local_stats, totals, sh
 
     def barrier():
@@ -278,11 +339,11 @@ def search_workload(args, rank, world, local, dist):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         once()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         local_stats, totals, sh = once()
     barrier()
     t1 = time.perf_counter()
@@ -292,7 +353,8 @@ def search_workload(args, rank, world, local, dist):
     # the last step's clocks of every rank: where a rank's time went (diagnosis of the scaling runs)
     put_s, put_n = eng.put_cost()
     clocks = torch.tensor([sh.idle_fraction(), sh.seconds["total"], sh.seconds["seed"], sh.seconds["busy"],
-                           sh.seconds["exchange"], put_s, float(put_n), float(sh.exchanges), float(sh.early_exchanges)],
+                           sh.seconds["exchange"], put_s, float(put_n), float(sh.exchanges), float(sh.early_exchanges),
+                           float(sh.states_moved)],
                           dtype=torch.float64, device=comm).unsqueeze(0)
     if dist is not None:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -305,28 +367,98 @@ def search_workload(args, rank, world, local, dist):
         clocks = allc
     clocks = clocks.cpu().tolist()
     elapsed = float(el.item())
+    eng.close()
+    del eng
+    return {
+        "n_vars": n, "objective": int(model.objective), "seconds_per_search": elapsed / steps, "steps": steps, "warmup": warmup,
+        "totals": totals, "states_moved_between_ranks": int(moved.item()), "nodes_per_rank": share.cpu().tolist(),
+        "seeded_alike": sh.seeded_alike, "status_page": sh.page_used,
+        # one entry per rank, last step: idle = share of the time after seeding not spent inside the engine;
+        # put = csgpu_search_put (copy of seeded / stolen states into the pool)
+        "ranks": [{"idle_fraction": round(c[0], 4), "seconds": round(c[1], 6), "seed_seconds": round(c[2], 6),
+                   "busy_seconds": round(c[3], 6), "exchange_seconds": round(c[4], 6),
+                   "put_seconds": round(c[5], 6), "put_states": int(c[6]),
+                   "put_fraction": round(c[5] / c[1], 5) if c[1] > 0 else None,
+                   "transfers": int(c[7]), "early_exchanges": int(c[8]), "states_moved": int(c[9])} for c in clocks]}
+
+
+def group_info(args, world, dist):
+    """what the ranks of this run are and how they talk: the backend of the process group, the world size the group
+    itself reports (not the command line's), and how the ranks were started"""
+    return {"process_group": None if dist is None else dist.get_backend(),
+            "ranks_seen": 1 if dist is None else dist.get_world_size(), "comm": args.comm if dist is not None else None,
+            "launched_by": "bench.py itself (child processes)" if os.environ.get("CSOLVE_BENCH_SELF_LAUNCHED") else
+                           ("an external launcher (torch.distributed.run)" if world > 1 else "a single process"),
+            "same_device": bool(args.same_device)}
+
+
+def search_workload(args, rank, world, local, dist):
+    """BASELINE configs[3]-style run as the headline: queens-N ALL (or a schedule.txt-style MIN model), the whole
+    search tree sharded over the ranks.  Strong scaling: the tree is fixed, every step is one complete search."""
+    text = problems.queens(args.search_queens, args.search_objective)
+    what = f"queens-{args.search_queens} {args.search_objective}"
+    if args.search_schedule:
+        text = problems.schedule(args.search_schedule, 1)
+        what = f"schedule-{args.search_schedule} MIN (examples/schedule.txt style)"
+    r = run_sharded_search(args, rank, world, dist, text, args.steps, args.warmup, time_limit=args.time_limit,
+                           children=args.children, pool=args.pool, slice_iterations=args.slice,
+                           max_slices=args.search_slices)
+    totals = r["totals"]
     if rank == 0:
+        sec = r["seconds_per_search"]
         print(json.dumps({
             "metric": "constraint propagations/sec + nodes/sec, queens-N, 1/2/4/8 MI355X",
-            "value": totals["props"] * args.steps / elapsed, "unit": "propagations/s",
-            "nodes_per_s": totals["nodes"] * args.steps / elapsed, "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "value": totals["props"] / sec, "unit": "propagations/s",
+            "nodes_per_s": totals["nodes"] / sec, "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": sec * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": f"{what}, full search sharded GPU-per-subtree "
-                                   f"(BASELINE configs[{4 if args.search_schedule else 3}] shape)", "solutions": totals["solutions"],
-                       "best": totals.get("best") if args.search_schedule else None,
-                       "nodes": totals["nodes"], "cuts": totals["cuts"], "props": totals["props"],
-                       "iterations": totals["iterations"], "states_moved_between_ranks": int(moved.item()),
-                       "nodes_per_rank": share.cpu().tolist(), "comm": args.comm,
-                       "process_group": None if dist is None else dist.get_backend(), "timeout": bool(totals.get("timeout")),
-                       "stopped_after_slices": args.search_slices or None},
-            # one entry per rank, last step: idle = share of the time after seeding not spent inside the engine;
-            # put = csgpu_search_put (copy + rebuilding the forbidden sets of seeded / stolen states)
-            "ranks": [{"idle_fraction": round(c[0], 4), "seconds": round(c[1], 6), "seed_seconds": round(c[2], 6),
-                       "busy_seconds": round(c[3], 6), "exchange_seconds": round(c[4], 6),
-                       "put_seconds": round(c[5], 6), "put_states": int(c[6]),
-                       "put_fraction": round(c[5] / c[1], 5) if c[1] > 0 else None,
-                       "transfers": int(c[7]), "early_exchanges": int(c[8])} for c in clocks]}))
+            "config": dict({"workload": f"{what}, full search sharded GPU-per-subtree "
+                                        f"(BASELINE configs[{4 if args.search_schedule else 3}] shape)", "solutions": totals["solutions"],
+                            "best": totals.get("best") if args.search_schedule else None,
+                            "nodes": totals["nodes"], "cuts": totals["cuts"], "props": totals["props"],
+                            "iterations": totals["iterations"], "states_moved_between_ranks": r["states_moved_between_ranks"],
+                            "nodes_per_rank": r["nodes_per_rank"], "timeout": bool(totals.get("timeout")),
+                            "stopped_after_slices": args.search_slices or None}, **group_info(args, world, dist)),
+            "ranks": r["ranks"]}))
+
+
+def search_record(args, rank, world, dist):
+    """The sharded search next to the propagation headline, in EVERY line (N = 1 included, so that the driver's 1 / 2 / 4 / 8
+    runs form a curve with a base): BASELINE configs[3] -- queens-17 ALL, a fixed tree (95,815,104 solutions): strong scaling
+    (seconds per search must fall with N); queens-128 ALL under a time limit (the north-star instance: the tree is not
+    finished by anyone, nodes per second is the figure) -- and configs[4]: a schedule.txt-style MIN model, whose incumbent
+    travels between the ranks.  All ranks take part; every rank returns the same dict."""
+    out = dict(group_info(args, world, dist))
+    out["note"] = ("strong scaling of the sharded search (one process per GPU, subtrees stolen between ranks, incumbent shared): "
+                   "seconds_per_search of the fixed trees must fall with n_gpus; nodes_per_s is the whole job's")
+
+    def rec(name, text, steps, warmup, **kw):
+        r = run_sharded_search(args, rank, world, dist, text, steps, warmup, **kw)
+        t = r["totals"]
+        sec = r["seconds_per_search"]
+        out[name] = {"seconds_per_search": sec, "nodes_per_s": t["nodes"] / sec, "propagations_per_s": t["props"] / sec,
+                     "nodes": t["nodes"], "cuts": t["cuts"], "props": t["props"], "solutions": t["solutions"],
+                     "iterations": t["iterations"], "timeout": bool(t.get("timeout")), "steps": steps, "warmup": warmup,
+                     "states_moved_between_ranks": r["states_moved_between_ranks"], "nodes_per_rank": r["nodes_per_rank"],
+                     "seeded_alike": r["seeded_alike"], "status_page": r["status_page"], "ranks": r["ranks"]}
+        if kw.get("time_limit"):
+            out[name]["time_limit_s"] = kw["time_limit"]
+        if "best" in t and r["objective"] in (2, 3):
+            out[name]["best"] = t["best"]
+        return out[name]
+
+    q = args.search_queens
+    rec(f"queens{q}_all", problems.queens(q, "ALL"), steps=args.search_steps, warmup=1)
+    out[f"queens{q}_all"]["workload"] = f"queens-{q} ALL, the whole tree, sharded GPU-per-subtree (BASELINE configs[3] shape); strong scaling"
+    rec("queens128_all", problems.queens(128, "ALL"), steps=1, warmup=0, time_limit=args.search_time_limit)
+    out["queens128_all"]["workload"] = (f"queens-128 ALL stopped after {args.search_time_limit} s on every rank (the reference's -t): "
+                                        f"nodes explored per second by the whole job")
+    sched = args.search_record_schedule
+    if sched > 0:
+        rec(f"schedule{sched}_min", problems.schedule(sched, 1), steps=1, warmup=0)
+        out[f"schedule{sched}_min"]["workload"] = (f"schedule-{sched} MIN (examples/schedule.txt style, BASELINE configs[4] shape): the "
+                                                   f"incumbent bound travels between the ranks")
+    return out
 
 
 def main():
@@ -372,6 +504,11 @@ def main():
                     "256 for ANY / MIN / MAX; a rank that runs dry calls the exchange earlier through the status page)")
     ap.add_argument("--search-slices", type=int, default=0,
                     help="stop a search after this many slices (0 = run to the end): ALL on trees too large to finish")
+    ap.add_argument("--no-search", action="store_true", help="skip the `search` sub-record (the sharded search next to the "
+                    "propagation headline); profiles of the propagation kernels use it")
+    ap.add_argument("--search-steps", type=int, default=2, help="timed searches of the fixed tree in the `search` sub-record")
+    ap.add_argument("--search-time-limit", type=float, default=2.0, help="seconds of the queens-128 ALL run of the `search` sub-record")
+    ap.add_argument("--search-record-schedule", type=int, default=12, help="tasks of the MIN model of the `search` sub-record (0: none)")
     ap.add_argument("--comm", choices=["nccl", "gloo"], default="nccl")
     ap.add_argument("--same-device", action="store_true", help="all ranks on cuda:0 (rehearsal on a 1-GPU box, use --comm gloo)")
     args = ap.parse_args()
@@ -384,10 +521,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        # one process per GPU, started by the launcher: measuring one GPU under the label of N would be wrong,
-        # and starting the ranks from here would mean replacing a process that has already touched the GPU
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start the ranks with "
-                         f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...`")
+        # one process per GPU: measuring one GPU under the label of N would be wrong.  (Without WORLD_SIZE the ranks
+        # were started by _launch_ranks_if_needed before anything touched a GPU; a launcher's world must match --gpus.)
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: either let bench.py start its ranks (no WORLD_SIZE in "
+                         f"the environment) or start them with `python -m torch.distributed.run --nnodes=1 --nproc-per-node "
+                         f"{args.gpus} bench.py --gpus {args.gpus} ...`")
     if args.same_device:
         local = 0
     torch.cuda.set_device(local)
@@ -474,6 +612,12 @@ def main():
             e2e = end_to_end_record()
             if e2e is not None:
                 out["end_to_end"] = e2e
+    if not args.no_search and not (args.sudoku or args.schedule) and n_q == 64:
+        # the propagation buffers are not needed any more: the search engines take their place in HBM
+        legs.clear()
+        del head, model
+        torch.cuda.empty_cache()
+        out["search"] = search_record(args, rank, world, dist)
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

@@ -148,6 +148,7 @@ class ShardedSearch:
         self.want_page = status_page
         self.seed_on_every_rank = seed_on_every_rank
         self.page = None
+        self.page_used = False  # whether the ranks shared a StatusPage in the last run
         self.exchanges = 0
         self.early_exchanges = 0  # exchanges entered because a neighbour asked, before the slice was used up
         self.states_moved = 0
@@ -196,6 +197,7 @@ class ShardedSearch:
             os.unlink(path)  # the mappings keep it alive
         if everybody:
             self.page = page
+            self.page_used = True
         elif page is not None:
             page.close()
 

@@ -14,6 +14,7 @@
 #include "../../include/csolve_gpu.h"
 #include "cs_kernels.hip.h"
 #include "cs_shave.hip.h"
+#include "cs_step.hip.h"
 #include "cs_internal.h"
 
 static thread_local char g_err[512] = "";
@@ -620,6 +621,8 @@ static const void *ne_packed_kernel(int n_vars, int nw, int s3) {
 #undef CS_PICK_S
 }
 
+static const void *step_packed_kernel(int n_vars, int nw, int s3); /* below, with the step launcher */
+
 /* kernel 6: clauses per lane (1, 2, 4, 8) if the model has at most 512 clauses, else 0 */
 static int clause_rounds_cpl(const csgpu_model *m) {
   if (m->img == NULL || m->img->n_clauses <= 0 || m->img->n_clauses > 8 * CS_WAVE) return 0;
@@ -834,6 +837,12 @@ extern "C" int csgpu_model_finalize(csgpu_model *m) {
             rc = upload(rel, total * sizeof(uint16_t), (int **)&m->d_packed_tab);
             free(rel);
             if (rc) return rc;
+            {
+              const size_t step_lds = ((2 * bytes + 15) & ~(size_t)15) + (size_t)16 * ((1 + m->packed_nw) * 256 + CS_STEP_QN) * sizeof(unsigned);
+              if (step_lds <= 80u * 1024u &&
+                  (rc = lds_limit(step_lds, step_packed_kernel(h->n_vars, m->packed_nw, m->img->dense_slots == 3))))
+                return rc;
+            }
           }
         }
       }
@@ -899,6 +908,92 @@ extern "C" const int32_t *csgpu_internal_root_lo(const csgpu_model *m) {
 }
 
 extern "C" int csgpu_model_forbidden_words(const csgpu_model *m) { return m && m->finalized ? m->fb_words : 0; }
+
+/* ---- cs_step.hip.h: one level of the search tree per launch ---- */
+static const void *step_packed_kernel(int n_vars, int nw, int s3) {
+#define CS_PICK_S(G, NW)                                                                           \
+  return s3 ? (const void *)cs_step_packed<G, NW, true> : (const void *)cs_step_packed<G, NW, false>;
+#define CS_PICK_NW(G)                                                                              \
+  if (nw == 1) { CS_PICK_S(G, 1) }                                                                 \
+  CS_PICK_S(G, 2)
+  if (n_vars <= 16) { CS_PICK_NW(4) }
+  CS_PICK_NW(2)
+#undef CS_PICK_NW
+#undef CS_PICK_S
+}
+
+/* LDS of a step workgroup of `waves` waves: the 16-bit table, then per wave the parent slots and the child queue */
+static size_t step_packed_lds(const csgpu_model *m, int waves) {
+  return ((2 * m->dense_bytes + 15) & ~(size_t)15) + (size_t)waves * ((1 + m->packed_nw) * 256 + CS_STEP_QN) * sizeof(unsigned);
+}
+
+extern "C" int csgpu_internal_step_kind(const csgpu_model *m) {
+  if (m == NULL || !m->finalized || m->img == NULL || m->d_packed_tab == NULL) return 0;
+  if (!(m->dense_waves && packed_nodes_per_wave(m->fb_words, m->host->n_vars, m->img->dense_width))) return 0;
+  if (step_packed_lds(m, 16) > 80u * 1024u) return 0; /* two workgroups of sixteen waves per CU */
+  return 1;
+}
+
+extern "C" int64_t csgpu_internal_step_waves(const csgpu_model *m) { return m == NULL ? 0 : (int64_t)m->n_cus * 32; }
+
+extern "C" int csgpu_internal_step(const csgpu_model *m, const csgpu_step_launch *L, void *stream) {
+  if (csgpu_internal_step_kind(m) != 1 || L == NULL || L->parents < 1) return set_err(CSGPU_E_ARG, "bad argument");
+  const int n = m->host->n_vars;
+  const int G = n <= 16 ? 4 : 2;
+  int maxw = 2;
+  for (int32_t v = 0; v < n; v++) {
+    const int64_t w = (int64_t)m->host->dom[v].hi - (int64_t)m->host->dom[v].lo + 1;
+    if (w > maxw) maxw = (int)w;
+  }
+  if (G * maxw > CS_STEP_QN) return set_err(CSGPU_E_LIMIT, "step kernel: interval too wide for the child queue");
+  /* waves: the machine's, fewer when the staging buffer would leave a wave less than two rounds of worst-case children;
+   * and no more than the parents need */
+  int64_t waves = (int64_t)m->n_cus * 32;
+  const int64_t by_stage = L->stage_rows / (2 * (int64_t)G * maxw);
+  if (waves > by_stage) waves = by_stage;
+  const int64_t by_parents = ((int64_t)L->parents + G - 1) / G;
+  if (waves > by_parents) waves = by_parents;
+  if (waves < 1) return set_err(CSGPU_E_LIMIT, "step kernel: staging buffer too small");
+  int wg_waves = 16;
+  while (wg_waves > waves) wg_waves >>= 1;
+  const int64_t grid = waves / wg_waves;
+  waves = grid * wg_waves;
+  const int64_t K = L->stage_rows / waves;
+  /* parents per ticket: about eight tickets per wave, at most 32 parents, and a chunk's worst case fits half a region */
+  int64_t chunk = (int64_t)L->parents / (waves * 8);
+  if (chunk > 32) chunk = 32;
+  if (chunk * maxw > K / 2) chunk = K / (2 * maxw);
+  chunk = chunk / G * G;
+  if (chunk < G) chunk = G;
+  cs_step_io io;
+  io.pool = (const cs_val *)L->pool;
+  io.first_row = (long long)L->first_row;
+  io.parents = L->parents;
+  io.chunk = (int)chunk;
+  io.maxw = maxw;
+  io.stage = (cs_val *)L->stage;
+  io.K = (int)(K > 0x7fffffff ? 0x7fffffff : K);
+  io.fill = L->fill;
+  io.wstat = (unsigned long long *)L->wstat;
+  io.ticket = L->ticket;
+  io.solutions = L->solutions;
+  io.stored = (unsigned long long *)L->stored;
+  io.max_solutions = (long long)L->max_solutions;
+  io.store_open = L->store_open;
+  int nn = n, slots = m->img->dense_slots, bias = m->packed_bias;
+  const void *tab_d = m->d_packed_tab;
+  const int *root_lo_d = m->d_root_lo, *sym_off = m->d_sym_off;
+  size_t tab_bytes = 2 * m->dense_bytes;
+  void *args[] = { &nn, &tab_d, &slots, &root_lo_d, &sym_off, &bias, &tab_bytes, &io };
+  HIP_TRY(hipLaunchKernel(step_packed_kernel(n, m->packed_nw, slots == 3), dim3((unsigned)grid),
+                          dim3((unsigned)(wg_waves * CS_WAVE)), args, step_packed_lds(m, wg_waves), (hipStream_t)stream));
+  hipLaunchKernelGGL(cs_collect, dim3((unsigned)waves), dim3(256), 0, (hipStream_t)stream, (const unsigned *)L->fill, (int)waves,
+                     (const cs_val *)L->stage, io.K, n, (cs_val *)L->pool, (long long)L->first_row, (int)L->parents,
+                     (int)chunk, (const unsigned *)L->ticket, (const unsigned long long *)L->wstat,
+                     (unsigned long long *)L->out, (const unsigned long long *)L->stored);
+  HIP_TRY(hipGetLastError());
+  return CSGPU_OK;
+}
 
 /* the register-resident forbidden-set kernel (kernel 4); sets_only: the states are the sets alone */
 static int launch_regs(const csgpu_model *m, const csgpu_val *d_states_in, const uint64_t *d_forb_in,

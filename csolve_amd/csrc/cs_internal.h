@@ -36,6 +36,30 @@ const int32_t *csgpu_internal_root_lo(const csgpu_model *m);
 int csgpu_internal_eval_list(const csgpu_model *m, const csgpu_val *d_states, const int32_t *d_list,
                              const uint64_t *d_count, int64_t bound, int32_t *d_truth, void *stream);
 
+/* ---- one level of the search tree in one launch (cs_step.hip.h): branch + fixpoints of the children + store ---- */
+typedef struct csgpu_step_launch {
+  const csgpu_val *pool;  /* parents: rows first_row .. first_row + parents - 1, drawn from the top down */
+  int64_t first_row;
+  int32_t parents;
+  csgpu_val *stage;       /* staging rows for the survivors (private regions per wave) */
+  int64_t stage_rows;
+  uint32_t *fill;         /* [csgpu_internal_step_waves] */
+  uint64_t *wstat;        /* [csgpu_internal_step_waves][8] */
+  uint32_t *ticket;       /* one word, zero at launch */
+  uint64_t *out;          /* [8]: consumed parents, survivors, nodes, cuts, props, revisions, solutions, stored */
+  int32_t *solutions;     /* [max_solutions][n_vars] */
+  uint64_t *stored;
+  int64_t max_solutions;
+  int32_t store_open;
+} csgpu_step_launch;
+/* 0: the model has no step kernel; 1: cs_step_packed (pure != network of at most 32 variables) */
+int csgpu_internal_step_kind(const csgpu_model *m);
+/* waves of the largest grid a step launch uses (sizes fill / wstat) */
+int64_t csgpu_internal_step_waves(const csgpu_model *m);
+/* the step kernel over the parents, then cs_collect: survivors appended to the pool behind the parents nobody drew,
+ * totals in out[] */
+int csgpu_internal_step(const csgpu_model *m, const csgpu_step_launch *L, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

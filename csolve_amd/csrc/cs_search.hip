@@ -97,6 +97,14 @@ struct csgpu_search {
   hipGraphExec_t burst_exec;
   int64_t burst_limit; /* parents per iteration the graph was built for (0: none) */
   cs_holes holes;      /* values a parent's own set forbids are cut without a launch (one set word per variable) */
+  /* fused levels (cs_step.hip.h): ALL on models with a step kernel -- the pool holds interval rows only, a frontier is
+   * one launch (branch + fixpoints + store) plus cs_collect */
+  int fused;
+  int64_t stage_rows;           /* rows of d_child_states, the staging buffer of the survivors */
+  uint32_t *d_fill, *d_ticket;
+  uint64_t *d_wstat, *d_step_out, *h_step_out; /* h: pinned */
+  double surv_per_parent;       /* recent survivors per parent (sizes the next frontier) */
+  uint64_t stored_seen;         /* rows in the solution store after the last iteration */
   int burst_off;       /* CSGPU_SEARCH_BURST=0: every iteration driven from the host */
   int eval_always;     /* CSGPU_SEARCH_EVAL=1: complete children of pure != networks are evaluated all the same (tests) */
   int graph_off;       /* CSGPU_SEARCH_GRAPH=0: the launches of a burst enqueued one by one */
@@ -939,6 +947,8 @@ extern "C" void csgpu_search_free(csgpu_search *s) {
   (void)hipFree(s->seed);
   (void)hipFree(s->d_best_solution);
   (void)hipFree(s->d_burst);
+  (void)hipFree(s->d_fill); (void)hipFree(s->d_ticket); (void)hipFree(s->d_wstat); (void)hipFree(s->d_step_out);
+  if (s->h_step_out) (void)hipHostFree(s->h_step_out);
   if (s->h_burst) (void)hipHostFree(s->h_burst);
   if (s->burst_exec) (void)hipGraphExecDestroy(s->burst_exec);
   if (s->burst_stream) (void)hipStreamDestroy(s->burst_stream);
@@ -1001,6 +1011,25 @@ extern "C" int csgpu_search_create(const csgpu_model *m, int64_t pool_capacity, 
   }
   ALLOC(s->pool, row * (size_t)s->cap);
   s->fw = s->obj_var < 0 ? csgpu_model_forbidden_words(m) : 0;
+  {
+    const char *ef = getenv("CSGPU_SEARCH_FUSED"), *ev = getenv("CSGPU_SEARCH_EVAL");
+    s->fused = s->objective == CS_OBJ_ALL && csgpu_internal_step_kind(m) != 0 && !(ef != NULL && ef[0] == '0') &&
+               !(ev != NULL && ev[0] == '1');
+  }
+  s->stage_rows = max_children;
+  s->surv_per_parent = (double)s->max_width;
+  if (s->fused) {
+    s->fw = 0; /* interval rows only: no sets in the pool, nothing to rebuild for states put from outside */
+    const int64_t waves = csgpu_internal_step_waves(m);
+    ALLOC(s->d_fill, sizeof(uint32_t) * (size_t)waves);
+    ALLOC(s->d_wstat, sizeof(uint64_t) * 8 * (size_t)waves);
+    ALLOC(s->d_ticket, 64);
+    ALLOC(s->d_step_out, sizeof(uint64_t) * 8);
+    if ((e = hipHostMalloc((void **)&s->h_step_out, sizeof(uint64_t) * 8, 0)) != hipSuccess) {
+      csgpu_search_free(s);
+      return fail(CSGPU_E_HIP, hipGetErrorString(e));
+    }
+  }
   if (s->fw > 0) {
     ALLOC(s->pool_forb, (size_t)n * s->fw * 8 * (size_t)s->cap);
     ALLOC(s->d_child_forb, (size_t)n * s->fw * 8 * (size_t)max_children);
@@ -1013,7 +1042,7 @@ extern "C" int csgpu_search_create(const csgpu_model *m, int64_t pool_capacity, 
   ALLOC(s->d_block_skip, sizeof(int) * ((size_t)max_children + 1));
   ALLOC(s->d_nodes, sizeof(csgpu_node) * (size_t)max_children);
   ALLOC(s->d_child_states, row * (size_t)max_children);
-  ALLOC(s->d_complete_states, row * (size_t)max_children);
+  if (!s->fused) ALLOC(s->d_complete_states, row * (size_t)max_children);
   ALLOC(s->d_results, sizeof(csgpu_result) * (size_t)max_children);
   ALLOC(s->d_dest, sizeof(int) * (size_t)max_children);
   ALLOC(s->d_complete_list, sizeof(int) * (size_t)max_children);
@@ -1134,6 +1163,8 @@ extern "C" int csgpu_search_reset(csgpu_search *s) {
   s->put_states = 0;
   s->have_best_solution = 0;
   s->pending_complete = 0;
+  s->surv_per_parent = (double)s->max_width;
+  s->stored_seen = 0;
   HIP_OK(hipMemset(s->d_counters, 0, sizeof(unsigned long long) * C_COUNT));
   HIP_OK(hipMemcpy(s->d_best, &s->st.best, sizeof(int), hipMemcpyHostToDevice));
   return CSGPU_OK;
@@ -1259,7 +1290,69 @@ static int flush_accept_results(csgpu_search *s) {
   return apply_accept_results(s, tail[0], (int)(unsigned)tail[C_BEST - C_SOLUTIONS]);
 }
 
+/* ALL on a model with a step kernel: the newest `parents` rows of the pool are one frontier, expanded by one launch.
+ * How many: as many as the pool and the staging buffer are likely to have room for the survivors of (the recent
+ * survivors per parent size the attempt; a wave that could overflow its region stops drawing parents and the
+ * undrawn ones stay where they are, so a wrong guess costs time, never a state). */
+static int one_iteration_fused(csgpu_search *s) {
+  const int64_t reserve = (int64_t)s->n * s->max_width;
+  const double spp = s->surv_per_parent < 0.25 ? 0.25 : s->surv_per_parent;
+  int64_t parents = s->top;
+  /* staging: expect spp survivors per parent, keep a factor of two in hand */
+  const int64_t by_stage = (int64_t)((double)s->stage_rows / (2.0 * spp));
+  if (parents > by_stage) parents = by_stage;
+  /* pool: a depth-first walk in batches of P holds about P * spp rows per level that is still open below the
+   * frontier (at most n levels); leave that much room, shrink P as the pool fills */
+  const int64_t room = s->cap - s->top - reserve;
+  const int64_t by_pool = room > 0 ? (int64_t)((double)room / (spp * (double)s->n)) : 0;
+  if (parents > by_pool) parents = by_pool;
+  if (parents > 0x3fffffff) parents = 0x3fffffff;
+  if (parents < 1) parents = 1;
+  if (s->top - parents + parents * s->max_width > s->cap && parents > 1) parents = 1;
+  if (s->top - 1 + s->max_width > s->cap) return fail(CSGPU_E_LIMIT, "state pool is full");
+  csgpu_step_launch L;
+  L.pool = (const csgpu_val *)s->pool;
+  L.first_row = s->top - parents;
+  L.parents = (int32_t)parents;
+  L.stage = (csgpu_val *)s->d_child_states;
+  L.stage_rows = s->stage_rows;
+  /* the survivors land behind the undrawn parents: never more than the pool has room for */
+  if (L.stage_rows > s->cap - (s->top - parents)) L.stage_rows = s->cap - (s->top - parents);
+  L.fill = s->d_fill;
+  L.wstat = s->d_wstat;
+  L.ticket = s->d_ticket;
+  L.out = s->d_step_out;
+  L.solutions = s->d_solutions;
+  L.stored = (uint64_t *)(s->d_counters + C_STORED);
+  L.max_solutions = s->max_solutions;
+  L.store_open = s->stored_seen < (uint64_t)s->max_solutions;
+  HIP_OK(hipMemsetAsync(s->d_ticket, 0, sizeof(uint32_t), 0));
+  const int rc = csgpu_internal_step(s->m, &L, NULL);
+  if (rc != CSGPU_OK) return rc;
+  HIP_OK(hipMemcpyAsync(s->h_step_out, s->d_step_out, sizeof(uint64_t) * 8, hipMemcpyDeviceToHost, 0));
+  HIP_OK(hipStreamSynchronize(0));
+  const uint64_t *h = s->h_step_out;
+  const int64_t consumed = (int64_t)h[0], survivors = (int64_t)h[1];
+  if (consumed < 1) return fail(CSGPU_E_LIMIT, "internal: a frontier of the fused search consumed no parent");
+  s->top += survivors - consumed;
+  if (s->top > s->peak) s->peak = s->top;
+  s->st.iterations++;
+  s->st.nodes += h[2];
+  s->st.cuts += h[3];
+  s->st.props += h[4];
+  s->st.revisions += h[5];
+  s->st.solutions += h[6];
+  s->stored_seen = h[7];
+  s->surv_per_parent = 0.5 * s->surv_per_parent + 0.5 * ((double)survivors / (double)consumed);
+  if (getenv("CSGPU_SEARCH_TRACE") != NULL)
+    fprintf(stderr, "fused: parents %lld consumed %lld survivors %lld top %lld nodes %llu cuts %llu solutions %llu\n",
+            (long long)parents, (long long)consumed, (long long)survivors, (long long)s->top, (unsigned long long)h[2],
+            (unsigned long long)h[3], (unsigned long long)h[6]);
+  return CSGPU_OK;
+}
+
 static int one_iteration(csgpu_search *s) {
+  if (s->fused) return one_iteration_fused(s);
   const int n = s->n;
   int64_t parents = s->top < s->parents_limit ? s->top : s->parents_limit;
   const int64_t reserve = (int64_t)s->n * s->max_width;

@@ -1,0 +1,371 @@
+/* cs_step.hip.h -- one level of the search tree in ONE launch: branch + propagate_clauses of every child + store.
+ *
+ * What the reference does per open node (solve(), reference src/csolve.c:398-476): pick a variable, try every
+ * value of its interval (step_val 331-338), bind + propagate_clauses per value (check_assignment 247-261), count
+ * CALLS / CUTS (65-73, 255-258), descend into the consistent ones.  The engine of round 1/2 did this as eight
+ * launches per frontier (branch, scan, emit, fixpoint, classify x 3, scatter) with every intermediate -- node
+ * records, child states, results, survivor lists -- written to and read back from HBM; the fixpoint was half of the
+ * device time (profiles/r02_h_kernel_stats_search_q16.csv).  Here a frontier is one launch of persistent waves:
+ *
+ *   parents   rows of the pool (`struct val_t` per variable, nothing else), handed out by tickets: one atomic per
+ *             `chunk` parents, ticket 0 = the newest rows, so that whatever is left undrawn is a prefix of the pool;
+ *   branch    the open variable with the smallest interval, ties lowest index (cs_branch_seg's rule);
+ *   holes     a value a valued neighbour of the branching variable forbids is counted as a node and a cut without a
+ *             fixpoint (the child "x = that value" fails at its first revision);
+ *   children  their fixpoints are computed from the parent's registers / LDS copy, never from HBM;
+ *   survivors consistent children with open variables go to the wave's PRIVATE region of the staging buffer -- no
+ *             allocation atomics, no lists; complete ones are solutions (on a pure != network a complete consistent
+ *             node satisfies every clause: each clause between two valued variables was revised when the second became
+ *             a value, propagate_eq_false_lr, propagate.c:106-120);
+ *   counters  per wave, written once at exit; `cs_collect` (one more launch) appends the regions to the pool and adds
+ *             the counters up.
+ * A wave stops drawing parents when its region could overflow; the parents nobody drew stay in the pool.
+ *
+ * cs_step_packed<G, NW, S3>: models of at most 32 variables (G = 4 segments of 16 lanes, or 2 of 32), the forbidden-set
+ * fixpoint of kernel 5 (cs_kernels.hip.h).  A parent's sets are rebuilt ONCE from its valued variables when it is
+ * loaded and kept, with its bounds, in a slot of LDS; its children (descriptors {slot, variable, value} in a queue of
+ * the wave's own in LDS) start from there.  Branching works on G parents at a time, the fixpoints on G children at a
+ * time, whichever parents they belong to: the lanes stay full although parents have different numbers of children.
+ */
+#ifndef CS_STEP_HIP_H
+#define CS_STEP_HIP_H
+
+#include "cs_kernels.hip.h"
+
+#define CS_STEP_QN 256      /* child descriptors a wave can hold (power of two) */
+#define CS_STEP_STATS 8     /* words per wave in wstat: nodes, cuts, props, revisions, solutions, parents, 0, 0 */
+
+struct cs_step_io {
+  const cs_val *pool;        /* parents: rows first_row .. first_row + parents - 1; ticket order is from the top down */
+  long long first_row;
+  int parents;
+  int chunk;                 /* parents per ticket (a multiple of G) */
+  int maxw;                  /* widest root interval: children of one parent at most */
+  cs_val *stage;             /* survivors: wave w owns rows w * K .. w * K + K - 1 */
+  int K;
+  unsigned *fill;            /* [waves] rows wave w has written */
+  unsigned long long *wstat; /* [waves][CS_STEP_STATS] */
+  unsigned *ticket;          /* zero at launch; left at the number of tickets drawn */
+  int32_t *solutions;        /* [max_solutions][n] */
+  unsigned long long *stored;
+  long long max_solutions;
+  int store_open;            /* 0: the store is full, nobody asks for a slot */
+};
+
+/* segment-wide broadcast of lane `src` (segment-relative) through the LDS crossbar */
+template <int S>
+__device__ __forceinline__ unsigned cs_seg_bcast(unsigned x, int src, int lane) {
+  return (unsigned)__builtin_amdgcn_ds_bpermute(((lane & ~(S - 1)) + src) << 2, (int)x);
+}
+
+template <int G, int NW, bool S3>
+__global__ __launch_bounds__(1024, 8) void cs_step_packed(int n, const unsigned short *__restrict__ tab_g, int slots,
+                                                          const int *__restrict__ root_lo, const int *__restrict__ sym_off,
+                                                          int bias, size_t tab_bytes, cs_step_io io) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
+  typedef unsigned long long u64;
+  constexpr int S = CS_WAVE / G;
+  constexpr int W = CS_WAVE;          /* columns of the table */
+  constexpr int TOP = 32 * NW - 1;    /* highest relative value */
+  constexpr unsigned KEY_VALUE = (1u << 26) - 1u;
+  constexpr int LOG_S = G == 4 ? 4 : 5;
+  constexpr int WORDS = 1 + NW;       /* per lane and parent slot: bounds, set word(s) */
+  const int lane = threadIdx.x & (CS_WAVE - 1);
+  const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int waves_per_block = blockDim.x >> 6;
+  const int wave_global = (int)blockIdx.x * waves_per_block + wave_in_block;
+  unsigned short *s_tab = (unsigned short *)cs_lds;
+  {
+    const int vecs = (int)(tab_bytes / 16);
+    const uint4 *src = (const uint4 *)tab_g;
+    uint4 *dst = (uint4 *)cs_lds;
+    for (int i = threadIdx.x; i < vecs; i += blockDim.x) dst[i] = src[i];
+  }
+  /* the wave's own LDS: four groups of G parent slots (256 lanes' worth per word) and the child queue */
+  unsigned *s_wave = (unsigned *)(cs_lds + ((tab_bytes + 15) & ~(size_t)15)) + (size_t)wave_in_block * (WORDS * 256 + CS_STEP_QN);
+  unsigned *s_prl = s_wave;            /* [4][64] rl | rh << 8 */
+  unsigned *s_pf = s_wave + 256;       /* [NW][4][64] set words */
+  unsigned *s_q = s_wave + WORDS * 256; /* [CS_STEP_QN] slot | var << 8 | value << 16 */
+  __syncthreads();
+
+  const int g = lane >> LOG_S, v = lane & (S - 1);
+  const bool live = v < n;
+  const int vcl = live ? v : n - 1;
+  const int b0 = live ? root_lo[vcl] : 0;
+  const int deg = live ? sym_off[vcl + 1] - sym_off[vcl] : 0;
+  const unsigned key_base = ((unsigned)v << 26) + (unsigned)bias;
+  const int row_stride = slots * W * 2;
+
+  /* one push round: every pending lane's variable ORs the value it forbids into the sets of its own segment */
+  auto push_pending = [&](bool &pending, int rl, unsigned *fb) {
+    while (__ballot(pending) != 0ull) {
+      const unsigned key = cs_segment_min<S>(pending ? key_base + (unsigned)rl : 0xffffffffu);
+      const int ul = (int)(key >> 26);       /* 63: nothing pending in this segment */
+      const int cd = (int)(key & KEY_VALUE); /* then 2^26 - 1: selects no bit below */
+      pending = pending && v != ul;
+      const int ulc = ul < n ? ul : n - 1;
+      const unsigned char *row = (const unsigned char *)s_tab + ulc * row_stride + v * 2;
+      if (S3) {
+        const int e0 = (int)*(const unsigned short *)(row), e1 = (int)*(const unsigned short *)(row + W * 2),
+                  e2 = (int)*(const unsigned short *)(row + 2 * W * 2);
+        const unsigned b0_ = (unsigned)(cd - e0), b1_ = (unsigned)(cd - e1), b2_ = (unsigned)(cd - e2);
+        fb[0] |= (b0_ < 32u ? 1u << b0_ : 0u) | (b1_ < 32u ? 1u << b1_ : 0u) | (b2_ < 32u ? 1u << b2_ : 0u);
+        if (NW == 2)
+          fb[1] |= ((b0_ >> 5) == 1u ? 1u << (b0_ & 31u) : 0u) | ((b1_ >> 5) == 1u ? 1u << (b1_ & 31u) : 0u) |
+                   ((b2_ >> 5) == 1u ? 1u << (b2_ & 31u) : 0u);
+      } else {
+        for (int k = 0; k < slots; k++) {
+          const unsigned bit = (unsigned)(cd - (int)*(const unsigned short *)(row + (size_t)k * W * 2));
+          fb[0] |= bit < 32u ? 1u << bit : 0u;
+          if (NW == 2) fb[1] |= (bit >> 5) == 1u ? 1u << (bit & 31u) : 0u;
+        }
+      }
+    }
+  };
+
+  /* scalars of the wave */
+  int c_cur = 0, c_end = 0;   /* the chunk of parents being worked on (ticket order) */
+  int exhausted = 0;          /* no more tickets for this wave */
+  int qhead = 0, qlen = 0;    /* the child queue */
+  int grp_tail = 0;           /* next group of parent slots to fill (0 .. 3) */
+  int fill = 0;               /* rows written to the wave's region */
+  int store_open = io.store_open;
+  int acc_fail = 0, acc_sol = 0, acc_parents = 0;
+  int acc_nodes = 0, acc_skip = 0, acc_props = 0, acc_revs = 0; /* per lane, summed at the end */
+  const size_t region = (size_t)wave_global * (size_t)io.K;
+
+  for (;;) {
+    /* ---- groups of parent slots in use: those between the oldest queued child's and the last one filled ---- */
+    int grp_live = 0;
+    if (qlen > 0) {
+      const unsigned d0 = s_q[qhead];
+      const int grp_head = (int)((__builtin_amdgcn_readfirstlane((int)d0) & 0xff) >> (G == 4 ? 2 : 1));
+      grp_live = (grp_tail - grp_head) & 3;
+      if (grp_live == 0) grp_live = 4;
+    }
+    /* ---- A: G more parents, while there is room for their slots and their children ---- */
+    if (grp_live < 4 && qlen + G * io.maxw <= CS_STEP_QN) {
+      if (c_cur == c_end && !exhausted) {
+        if (fill + qlen + io.chunk * io.maxw <= io.K) {
+          unsigned t = 0;
+          if (lane == 0) t = __hip_atomic_fetch_add(io.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const long long first = (long long)__builtin_amdgcn_readfirstlane((int)t) * io.chunk;
+          if (first < (long long)io.parents) {
+            c_cur = (int)first;
+            c_end = first + io.chunk < (long long)io.parents ? (int)first + io.chunk : io.parents;
+          } else {
+            exhausted = 1;
+          }
+        } else {
+          exhausted = 1; /* the region could overflow: this wave draws no more (the undrawn parents stay in the pool) */
+        }
+      }
+      if (c_cur < c_end) {
+        const int pidx = c_cur + g;
+        const bool pvalid = pidx < c_end;
+        const int had = c_end - c_cur < G ? c_end - c_cur : G;
+        c_cur += had;
+        acc_parents += had;
+        const long long prow = io.first_row + (long long)io.parents - 1 - (long long)(pvalid ? pidx : c_cur - 1);
+        const cs_val pd = io.pool[(size_t)prow * n + vcl];
+        int rl = live ? pd.lo - b0 : 0, rh = live ? pd.hi - b0 : 0;
+        rl = rl < 0 ? 0 : (rl > TOP ? TOP : rl); /* states outside the root domain are not valid input: stay defined */
+        rh = rh < 0 ? 0 : (rh > TOP ? TOP : rh);
+        unsigned fb[2];
+        fb[0] = live ? 0u : 0xfffffffeu;
+        fb[1] = live ? 0u : 0xffffffffu;
+        /* the parent is a fixpoint: its sets are what its valued variables forbid */
+        bool pending = live && pvalid && rl == rh;
+        push_pending(pending, rl, fb);
+        /* the branching variable: smallest open interval, ties lowest index (cs_branch_seg) */
+        const bool open = live && pvalid && rl != rh;
+        const unsigned kmin = cs_segment_min<S>(open ? ((unsigned)(rh - rl) << 8) | (unsigned)v : 0xffffffffu);
+        const int bv = (int)(kmin & 0xffu);
+        const bool any_open = kmin != 0xffffffffu;
+        const unsigned prl = (unsigned)rl | ((unsigned)rh << 8);
+        const unsigned prl_b = cs_seg_bcast<S>(prl, bv & (S - 1), lane);
+        const unsigned f0_b = cs_seg_bcast<S>(fb[0], bv & (S - 1), lane);
+        const unsigned f1_b = NW == 2 ? cs_seg_bcast<S>(fb[1], bv & (S - 1), lane) : 0u;
+        const int rlb = (int)(prl_b & 0xffu), rhb = (int)((prl_b >> 8) & 0xffu);
+        /* values of [rlb, rhb] no valued neighbour forbids */
+        unsigned a0, a1 = 0u;
+        if (NW == 1) {
+          a0 = ~f0_b & (~0u << rlb) & (~0u >> (31 - rhb));
+        } else {
+          const unsigned lo_m0 = rlb < 32 ? ~0u << rlb : 0u, lo_m1 = rlb < 32 ? ~0u : ~0u << (rlb - 32);
+          const unsigned hi_m0 = rhb < 32 ? ~0u >> (31 - rhb) : ~0u, hi_m1 = rhb < 32 ? 0u : ~0u >> (63 - rhb);
+          a0 = ~f0_b & lo_m0 & hi_m0;
+          a1 = ~f1_b & lo_m1 & hi_m1;
+        }
+        if (!any_open) { a0 = 0u; a1 = 0u; }
+        const int width = any_open ? rhb - rlb + 1 : 0;
+        const int cnt = __popc(a0) + (NW == 2 ? __popc(a1) : 0);
+        if (v == 0) { acc_nodes += width; acc_skip += width - cnt; }
+        /* the parents' bounds and sets into their slots */
+        const int slot_lane = grp_tail * 64 + lane;
+        s_prl[slot_lane] = prl;
+        s_pf[slot_lane] = fb[0];
+        if (NW == 2) s_pf[256 + slot_lane] = fb[1];
+        /* the children into the queue: segment g's after those of the segments before it */
+        int off = 0, total = 0;
+#pragma unroll
+        for (int gg = 0; gg < G; gg++) {
+          const int c = __builtin_amdgcn_readlane(cnt, gg * S);
+          off += g > gg ? c : 0;
+          total += c;
+        }
+        const unsigned desc_base = (unsigned)(grp_tail * G + g) | ((unsigned)bv << 8);
+        const int qbase = qhead + qlen + off;
+#pragma unroll
+        for (int p = 0; p < (32 * NW) / S; p++) {
+          const int bit = v + p * S;
+          const unsigned word = (NW == 2 && bit >= 32) ? a1 : a0;
+          const int b5 = bit & 31;
+          if ((word >> b5) & 1u) {
+            int rank = __popc(word & ((1u << b5) - 1u));
+            if (NW == 2 && bit >= 32) rank += __popc(a0);
+            s_q[(qbase + rank) & (CS_STEP_QN - 1)] = desc_base | ((unsigned)bit << 16);
+          }
+        }
+        if (total > 0) {
+          qlen += total;
+          grp_tail = (grp_tail + 1) & 3;
+        }
+        continue; /* more parents if there is room, before the fixpoints */
+      }
+    }
+    if (qlen == 0) break; /* no parent left for this wave and nothing queued */
+
+    /* ---- B: the fixpoints of G children ---- */
+    const int take = qlen < G ? qlen : G;
+    const bool valid = g < take;
+    const unsigned d = s_q[(qhead + (valid ? g : 0)) & (CS_STEP_QN - 1)];
+    qhead = (qhead + take) & (CS_STEP_QN - 1);
+    qlen -= take;
+    const int slot = (int)(d & 0xffu), nvar = (int)((d >> 8) & 0xffu), nval = (int)(d >> 16);
+    const int src = slot * S + v; /* slot = group * G + segment: the lanes of that parent */
+    const unsigned prl = s_prl[src];
+    unsigned fb[2];
+    fb[0] = s_pf[src];
+    fb[1] = NW == 2 ? s_pf[256 + src] : 0xffffffffu;
+    int rl = (int)(prl & 0xffu), rh = (int)((prl >> 8) & 0xffu);
+    const bool mine = v == nvar;
+    if (mine) { rl = nval; rh = nval; }
+    const int rl0 = rl, rh0 = rh; /* the assignment itself is no propagation (kernel 4's reference point) */
+    bool pending = mine && valid;
+    const u64 validm = take >= G ? ~0ull : ((1ull << (take * S)) - 1ull); /* a scalar shift; segments past the queue's end idle */
+    u64 failedm = 0ull, pushedm = __ballot(pending);
+    for (;;) {
+      push_pending(pending, rl, fb);
+      int first, last;
+      bool bad;
+      if (NW == 1) {
+        const unsigned a = ~fb[0] & (~0u << rl) & (~0u >> (31 - rh));
+        bad = a == 0u;
+        first = __builtin_ctz(a | 0x80000000u);
+        last = 31 - __builtin_clz(a | 1u);
+      } else {
+        cs_set_bounds<2>(fb, rl, rh, &first, &last);
+        bad = last < 0;
+      }
+      const bool newly = !bad && first == last && rl != rh;
+      rl = bad ? rl : first;
+      rh = bad ? rh : last;
+      const u64 badm = __ballot(bad);
+      if (badm != 0ull) failedm |= cs_segments_any<G>(badm);
+      const u64 newm = __ballot(newly) & ~failedm & validm;
+      if (newm == 0ull) break;
+      pending = __builtin_amdgcn_inverse_ballot_w64(newm);
+      pushedm |= newm;
+    }
+    failedm &= validm;
+    const u64 openm = cs_segments_any<G>(__ballot(live && rl != rh)) & validm;
+    const u64 survm = openm & ~failedm, complm = validm & ~failedm & ~openm;
+    acc_fail += __popcll(failedm) >> LOG_S;
+    acc_props += valid ? (rl - rl0) + (rh0 - rh) : 0;
+    acc_revs += __builtin_amdgcn_inverse_ballot_w64(pushedm) ? deg : 0;
+    if (survm != 0ull) {
+      const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(survm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)survm, 0u)) >> LOG_S;
+      if (__builtin_amdgcn_inverse_ballot_w64(survm) && live)
+        io.stage[(region + (size_t)(fill + rank)) * n + v] = cs_interval(b0 + rl, b0 + rh);
+      fill += __popcll(survm) >> LOG_S;
+    }
+    if (complm != 0ull) {
+      const int ns = __popcll(complm) >> LOG_S;
+      acc_sol += ns;
+      if (store_open) { /* which solutions are kept may vary from run to run; their count does not */
+        unsigned long long s0 = 0ull;
+        if (lane == 0) s0 = atomicAdd(io.stored, (unsigned long long)ns);
+        const long long slot0 = (long long)(((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(s0 >> 32)) << 32) |
+                                            (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)s0));
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(complm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)complm, 0u)) >> LOG_S;
+        if (__builtin_amdgcn_inverse_ballot_w64(complm) && live && slot0 + rank < io.max_solutions)
+          io.solutions[(size_t)(slot0 + rank) * n + v] = b0 + rl;
+        if (slot0 + ns >= io.max_solutions) store_open = 0;
+      }
+    }
+  }
+  /* what the wave has to report: its fill and its counters */
+  const int nodes = cs_wave_sum(acc_nodes), skip = cs_wave_sum(acc_skip), props = cs_wave_sum(acc_props),
+            revs = cs_wave_sum(acc_revs);
+  if (lane == 0) {
+    io.fill[wave_global] = (unsigned)fill;
+    unsigned long long *st = io.wstat + (size_t)wave_global * CS_STEP_STATS;
+    st[0] = (unsigned long long)nodes;
+    st[1] = (unsigned long long)(skip + acc_fail);
+    st[2] = (unsigned long long)props;
+    st[3] = (unsigned long long)revs;
+    st[4] = (unsigned long long)acc_sol;
+    st[5] = (unsigned long long)acc_parents;
+  }
+}
+
+/* Appends the waves' regions to the pool (after the parents nobody drew) and adds the waves' counters up.
+ * Workgroup w: rows before region w's = sum of fill[0 .. w), then a flat copy of its fill[w] * n elements.
+ * out[0] = parents consumed, out[1] = survivors, out[2 ..] = nodes, cuts, props, revisions, solutions, out[7] = rows in
+ * the solution store (workgroup 0). */
+__global__ __launch_bounds__(256) void cs_collect(const unsigned *__restrict__ fill, int waves, const cs_val *__restrict__ stage,
+                                                  int K, int n, cs_val *__restrict__ pool, long long first_row, int parents,
+                                                  int chunk, const unsigned *__restrict__ ticket,
+                                                  const unsigned long long *__restrict__ wstat,
+                                                  unsigned long long *__restrict__ out,
+                                                  const unsigned long long *__restrict__ stored) {
+  __shared__ unsigned long long s_red[256];
+  const int w = blockIdx.x, t = threadIdx.x;
+  const unsigned long long drawn = (unsigned long long)*ticket * (unsigned long long)chunk;
+  const long long consumed = drawn < (unsigned long long)parents ? (long long)drawn : (long long)parents;
+  unsigned long long before = 0ull;
+  for (int i = t; i < w; i += 256) before += fill[i];
+  s_red[t] = before;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) {
+    if (t < d) s_red[t] += s_red[t + d];
+    __syncthreads();
+  }
+  before = s_red[0];
+  __syncthreads();
+  const size_t count = (size_t)fill[w] * n;
+  const cs_val *src = stage + (size_t)w * K * n;
+  cs_val *dst = pool + (size_t)(first_row + parents - consumed + (long long)before) * n;
+  for (size_t e = t; e < count; e += 256) dst[e] = src[e];
+  if (w == 0) {
+    for (int k = 0; k < 6; k++) {
+      unsigned long long x = 0ull;
+      for (int i = t; i < waves; i += 256) x += k < 5 ? wstat[(size_t)i * CS_STEP_STATS + k] : (unsigned long long)fill[i];
+      s_red[t] = x;
+      __syncthreads();
+      for (int d = 128; d > 0; d >>= 1) {
+        if (t < d) s_red[t] += s_red[t + d];
+        __syncthreads();
+      }
+      if (t == 0) out[k < 5 ? 2 + k : 1] = s_red[0];
+      __syncthreads();
+    }
+    if (t == 0) {
+      out[0] = (unsigned long long)consumed;
+      out[7] = *stored;
+    }
+  }
+}
+
+#endif

@@ -622,6 +622,7 @@ static const void *ne_packed_kernel(int n_vars, int nw, int s3) {
 }
 
 static const void *step_packed_kernel(int n_vars, int nw, int s3); /* below, with the step launcher */
+static const void *step_import_kernel(int n_vars, int nw, int s3);
 
 /* kernel 6: clauses per lane (1, 2, 4, 8) if the model has at most 512 clauses, else 0 */
 static int clause_rounds_cpl(const csgpu_model *m) {
@@ -840,7 +841,8 @@ extern "C" int csgpu_model_finalize(csgpu_model *m) {
             {
               const size_t step_lds = ((2 * bytes + 15) & ~(size_t)15) + (size_t)16 * ((1 + m->packed_nw) * 256 + CS_STEP_QN) * sizeof(unsigned);
               if (step_lds <= 80u * 1024u &&
-                  (rc = lds_limit(step_lds, step_packed_kernel(h->n_vars, m->packed_nw, m->img->dense_slots == 3))))
+                  ((rc = lds_limit(step_lds, step_packed_kernel(h->n_vars, m->packed_nw, m->img->dense_slots == 3))) ||
+                   (rc = lds_limit((2 * bytes + 15) & ~(size_t)15, step_import_kernel(h->n_vars, m->packed_nw, m->img->dense_slots == 3)))))
                 return rc;
             }
           }
@@ -922,6 +924,18 @@ static const void *step_packed_kernel(int n_vars, int nw, int s3) {
 #undef CS_PICK_S
 }
 
+static const void *step_import_kernel(int n_vars, int nw, int s3) {
+#define CS_PICK_S(G, NW)                                                                           \
+  return s3 ? (const void *)cs_step_import<G, NW, true> : (const void *)cs_step_import<G, NW, false>;
+#define CS_PICK_NW(G)                                                                              \
+  if (nw == 1) { CS_PICK_S(G, 1) }                                                                 \
+  CS_PICK_S(G, 2)
+  if (n_vars <= 16) { CS_PICK_NW(4) }
+  CS_PICK_NW(2)
+#undef CS_PICK_NW
+#undef CS_PICK_S
+}
+
 /* LDS of a step workgroup of `waves` waves: the 16-bit table, then per wave the parent slots and the child queue */
 static size_t step_packed_lds(const csgpu_model *m, int waves) {
   return ((2 * m->dense_bytes + 15) & ~(size_t)15) + (size_t)waves * ((1 + m->packed_nw) * 256 + CS_STEP_QN) * sizeof(unsigned);
@@ -966,12 +980,12 @@ extern "C" int csgpu_internal_step(const csgpu_model *m, const csgpu_step_launch
   chunk = chunk / G * G;
   if (chunk < G) chunk = G;
   cs_step_io io;
-  io.pool = (const cs_val *)L->pool;
+  io.pool = (const uint2 *)L->pool;
   io.first_row = (long long)L->first_row;
   io.parents = L->parents;
   io.chunk = (int)chunk;
   io.maxw = maxw;
-  io.stage = (cs_val *)L->stage;
+  io.stage = (uint2 *)L->stage;
   io.K = (int)(K > 0x7fffffff ? 0x7fffffff : K);
   io.fill = L->fill;
   io.wstat = (unsigned long long *)L->wstat;
@@ -988,9 +1002,43 @@ extern "C" int csgpu_internal_step(const csgpu_model *m, const csgpu_step_launch
   HIP_TRY(hipLaunchKernel(step_packed_kernel(n, m->packed_nw, slots == 3), dim3((unsigned)grid),
                           dim3((unsigned)(wg_waves * CS_WAVE)), args, step_packed_lds(m, wg_waves), (hipStream_t)stream));
   hipLaunchKernelGGL(cs_collect, dim3((unsigned)waves), dim3(256), 0, (hipStream_t)stream, (const unsigned *)L->fill, (int)waves,
-                     (const cs_val *)L->stage, io.K, n, (cs_val *)L->pool, (long long)L->first_row, (int)L->parents,
+                     (const uint2 *)L->stage, io.K, n, (uint2 *)L->pool, (long long)L->first_row, (int)L->parents,
                      (int)chunk, (const unsigned *)L->ticket, (const unsigned long long *)L->wstat,
                      (unsigned long long *)L->out, (const unsigned long long *)L->stored);
+  HIP_TRY(hipGetLastError());
+  return CSGPU_OK;
+}
+
+extern "C" int csgpu_internal_step_import(const csgpu_model *m, csgpu_val *d_rows, int64_t first_row, int64_t count,
+                                          void *stream) {
+  if (csgpu_internal_step_kind(m) != 1 || d_rows == NULL || count < 0) return set_err(CSGPU_E_ARG, "bad argument");
+  if (count == 0) return CSGPU_OK;
+  const int n = m->host->n_vars, G = n <= 16 ? 4 : 2;
+  int nn = n, slots = m->img->dense_slots, bias = m->packed_bias;
+  const void *tab_d = m->d_packed_tab;
+  const int *root_lo_d = m->d_root_lo;
+  size_t tab_bytes = 2 * m->dense_bytes;
+  long long fr = first_row, cnt = count;
+  int64_t grid = (count + (int64_t)G * 4 - 1) / ((int64_t)G * 4); /* four waves per workgroup, G rows per wave and step */
+  if (grid > (int64_t)m->n_cus * 8) grid = (int64_t)m->n_cus * 8;
+  void *args[] = { &nn, &tab_d, &slots, &root_lo_d, &bias, &tab_bytes, &d_rows, &fr, &cnt };
+  HIP_TRY(hipLaunchKernel(step_import_kernel(n, m->packed_nw, slots == 3), dim3((unsigned)grid), dim3(256), args,
+                          (tab_bytes + 15) & ~(size_t)15, (hipStream_t)stream));
+  return CSGPU_OK;
+}
+
+extern "C" int csgpu_internal_step_export(const csgpu_model *m, csgpu_val *d_rows, int64_t first_row, int64_t count,
+                                          void *stream) {
+  if (csgpu_internal_step_kind(m) != 1 || d_rows == NULL || count < 0) return set_err(CSGPU_E_ARG, "bad argument");
+  if (count == 0) return CSGPU_OK;
+  const int n = m->host->n_vars;
+  const long long elements = (long long)count * n;
+  uint2 *rows = (uint2 *)d_rows + (size_t)first_row * n;
+  const unsigned grid = (unsigned)((elements + 255) / 256);
+  if (m->packed_nw == 1)
+    hipLaunchKernelGGL(cs_step_export<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, (const int *)m->d_root_lo, rows, elements);
+  else
+    hipLaunchKernelGGL(cs_step_export<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, (const int *)m->d_root_lo, rows, elements);
   HIP_TRY(hipGetLastError());
   return CSGPU_OK;
 }

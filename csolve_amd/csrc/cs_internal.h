@@ -38,7 +38,7 @@ int csgpu_internal_eval_list(const csgpu_model *m, const csgpu_val *d_states, co
 
 /* ---- one level of the search tree in one launch (cs_step.hip.h): branch + fixpoints of the children + store ---- */
 typedef struct csgpu_step_launch {
-  const csgpu_val *pool;  /* parents: rows first_row .. first_row + parents - 1, drawn from the top down */
+  const csgpu_val *pool;  /* parents (engine rows): rows first_row .. first_row + parents - 1, drawn from the top down */
   int64_t first_row;
   int32_t parents;
   csgpu_val *stage;       /* staging rows for the survivors (private regions per wave) */
@@ -59,6 +59,12 @@ int64_t csgpu_internal_step_waves(const csgpu_model *m);
 /* the step kernel over the parents, then cs_collect: survivors appended to the pool behind the parents nobody drew,
  * totals in out[] */
 int csgpu_internal_step(const csgpu_model *m, const csgpu_step_launch *L, void *stream);
+/* The pool of that path holds ENGINE ROWS (8 bytes per variable like csgpu_val, in the step kernel's terms: bounds
+ * relative to the root and the forbidden-set word, cs_step.hip.h).  Conversion in place, rows [first_row, first_row +
+ * count) of d_rows: import = interval rows -> engine rows (states put from outside), export = the reverse (states
+ * taken away). */
+int csgpu_internal_step_import(const csgpu_model *m, csgpu_val *d_rows, int64_t first_row, int64_t count, void *stream);
+int csgpu_internal_step_export(const csgpu_model *m, csgpu_val *d_rows, int64_t first_row, int64_t count, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1112,6 +1112,10 @@ static int search_put(csgpu_search *s, const csgpu_val *d_states, int64_t count)
   if (count > 0)
     HIP_OK(hipMemcpy(s->pool + (size_t)s->top * s->n, d_states, (size_t)count * s->n * sizeof(cs_val),
                      hipMemcpyDeviceToDevice));
+  if (count > 0 && s->fused) { /* the pool of the fused path holds engine rows (cs_step.hip.h) */
+    const int rc = csgpu_internal_step_import(s->m, (csgpu_val *)s->pool, s->top, count, NULL);
+    if (rc != CSGPU_OK) return rc;
+  }
   if (count > 0 && s->fw > 0) {
     /* states arriving from outside (the root, another rank) carry no sets: rebuild them in place,
      * max_children rows at a time (the batch buffers are free between iterations) */
@@ -1196,6 +1200,11 @@ extern "C" int csgpu_search_take(csgpu_search *s, csgpu_val *d_states, int64_t m
   *count = k;
   if (k == 0) return CSGPU_OK;
   HIP_OK(hipMemcpy(d_states, s->pool, (size_t)k * s->n * sizeof(cs_val), hipMemcpyDeviceToDevice));
+  if (s->fused) { /* engine rows -> interval rows, in the caller's buffer */
+    const int rc = csgpu_internal_step_export(s->m, d_states, 0, k, NULL);
+    if (rc != CSGPU_OK) return rc;
+    HIP_OK(hipDeviceSynchronize());
+  }
   /* fill the hole at the bottom with the newest rows */
   const int64_t rest = s->top - k, mv = rest < k ? rest : k;
   if (mv > 0) {
@@ -1308,7 +1317,8 @@ static int one_iteration_fused(csgpu_search *s) {
   if (parents > by_pool) parents = by_pool;
   if (parents > 0x3fffffff) parents = 0x3fffffff;
   if (parents < 1) parents = 1;
-  if (s->top - parents + parents * s->max_width > s->cap && parents > 1) parents = 1;
+  /* (no worst-case test "every child of every parent survives": the staging rows handed to the launch below are
+   * capped by what the pool has room for, and a wave whose region could overflow stops drawing parents) */
   if (s->top - 1 + s->max_width > s->cap) return fail(CSGPU_E_LIMIT, "state pool is full");
   csgpu_step_launch L;
   L.pool = (const csgpu_val *)s->pool;

@@ -22,10 +22,20 @@
  * A wave stops drawing parents when its region could overflow; the parents nobody drew stay in the pool.
  *
  * cs_step_packed<G, NW, S3>: models of at most 32 variables (G = 4 segments of 16 lanes, or 2 of 32), the forbidden-set
- * fixpoint of kernel 5 (cs_kernels.hip.h).  A parent's sets are rebuilt ONCE from its valued variables when it is
- * loaded and kept, with its bounds, in a slot of LDS; its children (descriptors {slot, variable, value} in a queue of
- * the wave's own in LDS) start from there.  Branching works on G parents at a time, the fixpoints on G children at a
- * time, whichever parents they belong to: the lanes stay full although parents have different numbers of children.
+ * fixpoint of kernel 5 (cs_kernels.hip.h).  A parent's bounds and sets go into a slot of LDS when it is loaded; its
+ * children (descriptors {slot, variable, value} in a queue of the wave's own in LDS) start from there.  Branching works
+ * on G parents at a time, the fixpoints on G children at a time, whichever parents they belong to: the lanes stay
+ * full although parents have different numbers of children.
+ *
+ * ENGINE ROWS.  The pool of this path holds 8 bytes per variable like `struct val_t`, but in the kernel's own terms,
+ * so that a parent needs no preparation (rebuilding a parent's sets from its valued variables, one push each, was a
+ * quarter of the first version's time):
+ *   NW = 1 (every root domain within 32 values): {set word, rl | rh << 8}  -- bounds relative to the root lower bound;
+ *   NW = 2 (within 64 values):                   {set word 0, set word 1}  -- every value outside the interval marked,
+ *                                                                             the interval is [first, last unmarked].
+ * The set of a fixpoint is exactly what its valued variables forbid, and a child's final registers hold it.
+ * cs_step_import turns interval rows (states put from outside: the root, stolen states) into engine rows,
+ * cs_step_export does the reverse (states taken away); both in place.
  */
 #ifndef CS_STEP_HIP_H
 #define CS_STEP_HIP_H
@@ -36,12 +46,12 @@
 #define CS_STEP_STATS 8     /* words per wave in wstat: nodes, cuts, props, revisions, solutions, parents, 0, 0 */
 
 struct cs_step_io {
-  const cs_val *pool;        /* parents: rows first_row .. first_row + parents - 1; ticket order is from the top down */
+  const uint2 *pool;         /* parents (engine rows): rows first_row .. first_row + parents - 1; ticket order is from the top down */
   long long first_row;
   int parents;
   int chunk;                 /* parents per ticket (a multiple of G) */
   int maxw;                  /* widest root interval: children of one parent at most */
-  cs_val *stage;             /* survivors: wave w owns rows w * K .. w * K + K - 1 */
+  uint2 *stage;              /* survivors (engine rows): wave w owns rows w * K .. w * K + K - 1 */
   int K;
   unsigned *fill;            /* [waves] rows wave w has written */
   unsigned long long *wstat; /* [waves][CS_STEP_STATS] */
@@ -58,46 +68,17 @@ __device__ __forceinline__ unsigned cs_seg_bcast(unsigned x, int src, int lane) 
   return (unsigned)__builtin_amdgcn_ds_bpermute(((lane & ~(S - 1)) + src) << 2, (int)x);
 }
 
+/* what the packed kernels share: the table in LDS and the push of kernel 5 */
 template <int G, int NW, bool S3>
-__global__ __launch_bounds__(1024, 8) void cs_step_packed(int n, const unsigned short *__restrict__ tab_g, int slots,
-                                                          const int *__restrict__ root_lo, const int *__restrict__ sym_off,
-                                                          int bias, size_t tab_bytes, cs_step_io io) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
-  typedef unsigned long long u64;
-  constexpr int S = CS_WAVE / G;
-  constexpr int W = CS_WAVE;          /* columns of the table */
-  constexpr int TOP = 32 * NW - 1;    /* highest relative value */
-  constexpr unsigned KEY_VALUE = (1u << 26) - 1u;
-  constexpr int LOG_S = G == 4 ? 4 : 5;
-  constexpr int WORDS = 1 + NW;       /* per lane and parent slot: bounds, set word(s) */
-  const int lane = threadIdx.x & (CS_WAVE - 1);
-  const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int waves_per_block = blockDim.x >> 6;
-  const int wave_global = (int)blockIdx.x * waves_per_block + wave_in_block;
-  unsigned short *s_tab = (unsigned short *)cs_lds;
-  {
-    const int vecs = (int)(tab_bytes / 16);
-    const uint4 *src = (const uint4 *)tab_g;
-    uint4 *dst = (uint4 *)cs_lds;
-    for (int i = threadIdx.x; i < vecs; i += blockDim.x) dst[i] = src[i];
-  }
-  /* the wave's own LDS: four groups of G parent slots (256 lanes' worth per word) and the child queue */
-  unsigned *s_wave = (unsigned *)(cs_lds + ((tab_bytes + 15) & ~(size_t)15)) + (size_t)wave_in_block * (WORDS * 256 + CS_STEP_QN);
-  unsigned *s_prl = s_wave;            /* [4][64] rl | rh << 8 */
-  unsigned *s_pf = s_wave + 256;       /* [NW][4][64] set words */
-  unsigned *s_q = s_wave + WORDS * 256; /* [CS_STEP_QN] slot | var << 8 | value << 16 */
-  __syncthreads();
-
-  const int g = lane >> LOG_S, v = lane & (S - 1);
-  const bool live = v < n;
-  const int vcl = live ? v : n - 1;
-  const int b0 = live ? root_lo[vcl] : 0;
-  const int deg = live ? sym_off[vcl + 1] - sym_off[vcl] : 0;
-  const unsigned key_base = ((unsigned)v << 26) + (unsigned)bias;
-  const int row_stride = slots * W * 2;
-
+struct cs_packed {
+  static constexpr int S = CS_WAVE / G;
+  static constexpr int W = CS_WAVE;
+  static constexpr unsigned KEY_VALUE = (1u << 26) - 1u;
+  const unsigned short *s_tab;
+  int n, slots, v, row_stride;
+  unsigned key_base;
   /* one push round: every pending lane's variable ORs the value it forbids into the sets of its own segment */
-  auto push_pending = [&](bool &pending, int rl, unsigned *fb) {
+  __device__ __forceinline__ void push_pending(bool &pending, int rl, unsigned *fb) const {
     while (__ballot(pending) != 0ull) {
       const unsigned key = cs_segment_min<S>(pending ? key_base + (unsigned)rl : 0xffffffffu);
       const int ul = (int)(key >> 26);       /* 63: nothing pending in this segment */
@@ -121,11 +102,71 @@ __global__ __launch_bounds__(1024, 8) void cs_step_packed(int n, const unsigned 
         }
       }
     }
-  };
+  }
+  /* engine row element <-> bounds and sets (a lane without a variable: the value 0, everything else forbidden) */
+  __device__ __forceinline__ void decode(uint2 e, bool live, int &rl, int &rh, unsigned *fb) const {
+    if (NW == 1) {
+      fb[0] = live ? e.x : 0xfffffffeu;
+      fb[1] = 0xffffffffu;
+      rl = live ? (int)(e.y & 0xffu) : 0;
+      rh = live ? (int)((e.y >> 8) & 0xffu) : 0;
+    } else {
+      fb[0] = live ? e.x : 0xfffffffeu;
+      fb[1] = live ? e.y : 0xffffffffu;
+      cs_set_bounds_all<2>(fb, &rl, &rh);
+      rl = rl > 63 ? 0 : rl; /* a row with nothing allowed is not valid input: stay defined */
+      rh = rh < 0 ? 0 : rh;
+    }
+  }
+  __device__ __forceinline__ uint2 encode(int rl, int rh, unsigned *fb) const {
+    if (NW == 1) return make_uint2(fb[0], (unsigned)rl | ((unsigned)rh << 8));
+    cs_set_restrict<2>(fb, rl, rh);
+    return make_uint2(fb[0], fb[1]);
+  }
+};
+
+template <int G, int NW, bool S3>
+__global__ __launch_bounds__(1024, 8) void cs_step_packed(int n, const unsigned short *__restrict__ tab_g, int slots,
+                                                          const int *__restrict__ root_lo, const int *__restrict__ sym_off,
+                                                          int bias, size_t tab_bytes, cs_step_io io) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
+  typedef unsigned long long u64;
+  constexpr int S = CS_WAVE / G;
+  constexpr int W = CS_WAVE;          /* columns of the table */
+  constexpr int LOG_S = G == 4 ? 4 : 5;
+  constexpr int WORDS = 1 + NW;       /* per lane and parent slot: bounds, set word(s) */
+  const int lane = threadIdx.x & (CS_WAVE - 1);
+  const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int waves_per_block = blockDim.x >> 6;
+  const int wave_global = (int)blockIdx.x * waves_per_block + wave_in_block;
+  {
+    const int vecs = (int)(tab_bytes / 16);
+    const uint4 *src = (const uint4 *)tab_g;
+    uint4 *dst = (uint4 *)cs_lds;
+    for (int i = threadIdx.x; i < vecs; i += blockDim.x) dst[i] = src[i];
+  }
+  /* the wave's own LDS: four groups of G parent slots (256 lanes' worth per word) and the child queue */
+  unsigned *s_wave = (unsigned *)(cs_lds + ((tab_bytes + 15) & ~(size_t)15)) + (size_t)wave_in_block * (WORDS * 256 + CS_STEP_QN);
+  unsigned *s_prl = s_wave;            /* [4][64] rl | rh << 8 */
+  unsigned *s_pf = s_wave + 256;       /* [NW][4][64] set words */
+  unsigned *s_q = s_wave + WORDS * 256; /* [CS_STEP_QN] slot | var << 8 | value << 16 */
+  __syncthreads();
+
+  const int g = lane >> LOG_S, v = lane & (S - 1);
+  const bool live = v < n;
+  const int vcl = live ? v : n - 1;
+  const int b0 = live ? root_lo[vcl] : 0;
+  const int deg = live ? sym_off[vcl + 1] - sym_off[vcl] : 0;
+  cs_packed<G, NW, S3> P;
+  P.s_tab = (const unsigned short *)cs_lds;
+  P.n = n; P.slots = slots; P.v = v; P.row_stride = slots * W * 2;
+  P.key_base = ((unsigned)v << 26) + (unsigned)bias;
 
   /* scalars of the wave */
   int c_cur = 0, c_end = 0;   /* the chunk of parents being worked on (ticket order) */
   int exhausted = 0;          /* no more tickets for this wave */
+  int tk_pending = 0;         /* a ticket has been asked for; it arrives in lane 0 of tk_v */
+  unsigned tk_v = 0u;
   int qhead = 0, qlen = 0;    /* the child queue */
   int grp_tail = 0;           /* next group of parent slots to fill (0 .. 3) */
   int fill = 0;               /* rows written to the wave's region */
@@ -133,8 +174,45 @@ __global__ __launch_bounds__(1024, 8) void cs_step_packed(int n, const unsigned 
   int acc_fail = 0, acc_sol = 0, acc_parents = 0;
   int acc_nodes = 0, acc_skip = 0, acc_props = 0, acc_revs = 0; /* per lane, summed at the end */
   const size_t region = (size_t)wave_global * (size_t)io.K;
+  uint2 pre = make_uint2(0u, 0u); /* the rows of the next G parents of the chunk, loaded one step ahead */
+
+  /* rows of the G parents from ticket position `first` on (segment g: first + g, clamped to the chunk) */
+  auto load_group = [&](int first, int end) -> uint2 {
+    const int pidx = first + g < end ? first + g : end - 1;
+    const long long prow = io.first_row + (long long)io.parents - 1 - (long long)pidx;
+    return io.pool[(size_t)prow * n + vcl];
+  };
+  /* ask for a ticket unless the region could overflow with what is queued, what is left of the chunk and a new chunk
+   * (a macro, not a lambda: captured by reference the flags end up in scratch memory) */
+#define CS_STEP_ASK_TICKET()                                                                                        \
+  do {                                                                                                              \
+    if (!exhausted && !tk_pending) {                                                                                \
+      if (fill + qlen + (c_end - c_cur + io.chunk) * io.maxw <= io.K) {                                             \
+        tk_v = 0u;                                                                                                  \
+        if (lane == 0) tk_v = __hip_atomic_fetch_add(io.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    \
+        tk_pending = 1;                                                                                             \
+      } else {                                                                                                      \
+        exhausted = 1; /* this wave draws no more: the undrawn parents stay in the pool */                          \
+      }                                                                                                             \
+    }                                                                                                               \
+  } while (0)
+  CS_STEP_ASK_TICKET();
 
   for (;;) {
+    /* the wave's bookkeeping is uniform by construction; say so (left to itself the compiler carries it in vector
+     * registers, compares it under exec masks and spills some of it to scratch) */
+    c_cur = __builtin_amdgcn_readfirstlane(c_cur);
+    c_end = __builtin_amdgcn_readfirstlane(c_end);
+    exhausted = __builtin_amdgcn_readfirstlane(exhausted);
+    tk_pending = __builtin_amdgcn_readfirstlane(tk_pending);
+    qhead = __builtin_amdgcn_readfirstlane(qhead);
+    qlen = __builtin_amdgcn_readfirstlane(qlen);
+    grp_tail = __builtin_amdgcn_readfirstlane(grp_tail);
+    fill = __builtin_amdgcn_readfirstlane(fill);
+    store_open = __builtin_amdgcn_readfirstlane(store_open);
+    acc_fail = __builtin_amdgcn_readfirstlane(acc_fail);
+    acc_sol = __builtin_amdgcn_readfirstlane(acc_sol);
+    acc_parents = __builtin_amdgcn_readfirstlane(acc_parents);
     /* ---- groups of parent slots in use: those between the oldest queued child's and the last one filled ---- */
     int grp_live = 0;
     if (qlen > 0) {
@@ -145,38 +223,28 @@ __global__ __launch_bounds__(1024, 8) void cs_step_packed(int n, const unsigned 
     }
     /* ---- A: G more parents, while there is room for their slots and their children ---- */
     if (grp_live < 4 && qlen + G * io.maxw <= CS_STEP_QN) {
-      if (c_cur == c_end && !exhausted) {
-        if (fill + qlen + io.chunk * io.maxw <= io.K) {
-          unsigned t = 0;
-          if (lane == 0) t = __hip_atomic_fetch_add(io.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const long long first = (long long)__builtin_amdgcn_readfirstlane((int)t) * io.chunk;
-          if (first < (long long)io.parents) {
-            c_cur = (int)first;
-            c_end = first + io.chunk < (long long)io.parents ? (int)first + io.chunk : io.parents;
-          } else {
-            exhausted = 1;
-          }
+      if (c_cur == c_end && tk_pending) { /* the chunk the ticket names */
+        tk_pending = 0;
+        const long long first = (long long)__builtin_amdgcn_readfirstlane((int)tk_v) * io.chunk;
+        if (first < (long long)io.parents) {
+          c_cur = (int)first;
+          c_end = first + io.chunk < (long long)io.parents ? (int)first + io.chunk : io.parents;
+          pre = load_group(c_cur, c_end);
         } else {
-          exhausted = 1; /* the region could overflow: this wave draws no more (the undrawn parents stay in the pool) */
+          exhausted = 1;
         }
       }
       if (c_cur < c_end) {
-        const int pidx = c_cur + g;
-        const bool pvalid = pidx < c_end;
+        const bool pvalid = c_cur + g < c_end;
         const int had = c_end - c_cur < G ? c_end - c_cur : G;
+        const uint2 e = pre;
         c_cur += had;
         acc_parents += had;
-        const long long prow = io.first_row + (long long)io.parents - 1 - (long long)(pvalid ? pidx : c_cur - 1);
-        const cs_val pd = io.pool[(size_t)prow * n + vcl];
-        int rl = live ? pd.lo - b0 : 0, rh = live ? pd.hi - b0 : 0;
-        rl = rl < 0 ? 0 : (rl > TOP ? TOP : rl); /* states outside the root domain are not valid input: stay defined */
-        rh = rh < 0 ? 0 : (rh > TOP ? TOP : rh);
+        if (c_cur < c_end) pre = load_group(c_cur, c_end); /* the next group's rows: in flight during this one's work */
+        else CS_STEP_ASK_TICKET();                         /* the next chunk's ticket likewise */
+        int rl, rh;
         unsigned fb[2];
-        fb[0] = live ? 0u : 0xfffffffeu;
-        fb[1] = live ? 0u : 0xffffffffu;
-        /* the parent is a fixpoint: its sets are what its valued variables forbid */
-        bool pending = live && pvalid && rl == rh;
-        push_pending(pending, rl, fb);
+        P.decode(e, live, rl, rh, fb);
         /* the branching variable: smallest open interval, ties lowest index (cs_branch_seg) */
         const bool open = live && pvalid && rl != rh;
         const unsigned kmin = cs_segment_min<S>(open ? ((unsigned)(rh - rl) << 8) | (unsigned)v : 0xffffffffu);
@@ -253,10 +321,13 @@ __global__ __launch_bounds__(1024, 8) void cs_step_packed(int n, const unsigned 
     if (mine) { rl = nval; rh = nval; }
     const int rl0 = rl, rh0 = rh; /* the assignment itself is no propagation (kernel 4's reference point) */
     bool pending = mine && valid;
-    const u64 validm = take >= G ? ~0ull : ((1ull << (take * S)) - 1ull); /* a scalar shift; segments past the queue's end idle */
+    /* the segments that hold a child (those past the queue's end idle); 32-bit halves: no 64-bit shift by a variable */
+    const unsigned valid_lo = G == 2 ? 0xffffffffu : (take >= 2 ? 0xffffffffu : 0x0000ffffu);
+    const unsigned valid_hi = G == 2 ? (take >= 2 ? 0xffffffffu : 0u) : (take >= 4 ? 0xffffffffu : (take == 3 ? 0x0000ffffu : 0u));
+    const u64 validm = ((u64)valid_hi << 32) | (u64)valid_lo;
     u64 failedm = 0ull, pushedm = __ballot(pending);
     for (;;) {
-      push_pending(pending, rl, fb);
+      P.push_pending(pending, rl, fb);
       int first, last;
       bool bad;
       if (NW == 1) {
@@ -286,8 +357,8 @@ __global__ __launch_bounds__(1024, 8) void cs_step_packed(int n, const unsigned 
     acc_revs += __builtin_amdgcn_inverse_ballot_w64(pushedm) ? deg : 0;
     if (survm != 0ull) {
       const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(survm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)survm, 0u)) >> LOG_S;
-      if (__builtin_amdgcn_inverse_ballot_w64(survm) && live)
-        io.stage[(region + (size_t)(fill + rank)) * n + v] = cs_interval(b0 + rl, b0 + rh);
+      const uint2 e = P.encode(rl, rh, fb);
+      if (__builtin_amdgcn_inverse_ballot_w64(survm) && live) io.stage[(region + (size_t)(fill + rank)) * n + v] = e;
       fill += __popcll(survm) >> LOG_S;
     }
     if (complm != 0ull) {
@@ -318,14 +389,79 @@ __global__ __launch_bounds__(1024, 8) void cs_step_packed(int n, const unsigned 
     st[4] = (unsigned long long)acc_sol;
     st[5] = (unsigned long long)acc_parents;
   }
+#undef CS_STEP_ASK_TICKET
+}
+
+/* interval rows -> engine rows, in place (rows [first_row, first_row + count) of `rows`): the sets of a fixpoint are
+ * what its valued variables forbid; one segment per row, grid-stride */
+template <int G, int NW, bool S3>
+__global__ __launch_bounds__(256) void cs_step_import(int n, const unsigned short *__restrict__ tab_g, int slots,
+                                                      const int *__restrict__ root_lo, int bias, size_t tab_bytes,
+                                                      uint2 *__restrict__ rows, long long first_row, long long count) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
+  constexpr int S = CS_WAVE / G;
+  constexpr int TOP = 32 * NW - 1;
+  {
+    const int vecs = (int)(tab_bytes / 16);
+    const uint4 *src = (const uint4 *)tab_g;
+    uint4 *dst = (uint4 *)cs_lds;
+    for (int i = threadIdx.x; i < vecs; i += blockDim.x) dst[i] = src[i];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & (CS_WAVE - 1);
+  const int v = lane & (S - 1);
+  const bool live = v < n;
+  const int vcl = live ? v : n - 1;
+  const int b0 = live ? root_lo[vcl] : 0;
+  cs_packed<G, NW, S3> P;
+  P.s_tab = (const unsigned short *)cs_lds;
+  P.n = n; P.slots = slots; P.v = v; P.row_stride = slots * CS_WAVE * 2;
+  P.key_base = ((unsigned)v << 26) + (unsigned)bias;
+  const long long segs = (long long)gridDim.x * (blockDim.x / S);
+  const long long groups = (count + G - 1) / G; /* whole waves iterate together */
+  for (long long q = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); q < groups; q += segs / G) {
+    const long long r = q * G + lane / S;
+    const bool valid = r < count;
+    const size_t at = (size_t)(first_row + (valid ? r : count - 1)) * n + vcl;
+    const cs_val d = ((const cs_val *)rows)[at];
+    int rl = live ? d.lo - b0 : 0, rh = live ? d.hi - b0 : 0;
+    rl = rl < 0 ? 0 : (rl > TOP ? TOP : rl); /* states outside the root domain are not valid input: stay defined */
+    rh = rh < 0 ? 0 : (rh > TOP ? TOP : rh);
+    unsigned fb[2];
+    fb[0] = live ? 0u : 0xfffffffeu;
+    fb[1] = live ? 0u : 0xffffffffu;
+    bool pending = live && valid && rl == rh;
+    P.push_pending(pending, rl, fb);
+    const uint2 e = P.encode(rl, rh, fb);
+    if (valid && live) rows[at] = e;
+  }
+}
+
+/* engine rows -> interval rows, in place: one thread per element */
+template <int NW>
+__global__ __launch_bounds__(256) void cs_step_export(int n, const int *__restrict__ root_lo, uint2 *__restrict__ rows,
+                                                      long long elements) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= elements) return;
+  const uint2 e = rows[i];
+  const int b0 = root_lo[(int)(i % n)];
+  int rl, rh;
+  if (NW == 1) {
+    rl = (int)(e.y & 0xffu);
+    rh = (int)((e.y >> 8) & 0xffu);
+  } else {
+    unsigned fb[2] = { e.x, e.y };
+    cs_set_bounds_all<2>(fb, &rl, &rh);
+  }
+  ((cs_val *)rows)[i] = cs_interval(b0 + rl, b0 + rh);
 }
 
 /* Appends the waves' regions to the pool (after the parents nobody drew) and adds the waves' counters up.
  * Workgroup w: rows before region w's = sum of fill[0 .. w), then a flat copy of its fill[w] * n elements.
  * out[0] = parents consumed, out[1] = survivors, out[2 ..] = nodes, cuts, props, revisions, solutions, out[7] = rows in
  * the solution store (workgroup 0). */
-__global__ __launch_bounds__(256) void cs_collect(const unsigned *__restrict__ fill, int waves, const cs_val *__restrict__ stage,
-                                                  int K, int n, cs_val *__restrict__ pool, long long first_row, int parents,
+__global__ __launch_bounds__(256) void cs_collect(const unsigned *__restrict__ fill, int waves, const uint2 *__restrict__ stage,
+                                                  int K, int n, uint2 *__restrict__ pool, long long first_row, int parents,
                                                   int chunk, const unsigned *__restrict__ ticket,
                                                   const unsigned long long *__restrict__ wstat,
                                                   unsigned long long *__restrict__ out,
@@ -345,9 +481,14 @@ __global__ __launch_bounds__(256) void cs_collect(const unsigned *__restrict__ f
   before = s_red[0];
   __syncthreads();
   const size_t count = (size_t)fill[w] * n;
-  const cs_val *src = stage + (size_t)w * K * n;
-  cs_val *dst = pool + (size_t)(first_row + parents - consumed + (long long)before) * n;
-  for (size_t e = t; e < count; e += 256) dst[e] = src[e];
+  const uint2 *src = stage + (size_t)w * K * n;
+  uint2 *dst = pool + (size_t)(first_row + parents - consumed + (long long)before) * n;
+  size_t e = t;
+  for (; e + 768 < count; e += 1024) { /* four loads in flight per thread */
+    const uint2 a = src[e], b = src[e + 256], c = src[e + 512], d = src[e + 768];
+    dst[e] = a; dst[e + 256] = b; dst[e + 512] = c; dst[e + 768] = d;
+  }
+  for (; e < count; e += 256) dst[e] = src[e];
   if (w == 0) {
     for (int k = 0; k < 6; k++) {
       unsigned long long x = 0ull;

@@ -317,7 +317,11 @@ def test_lanes_on_one_gpu_reach_the_same_results():
         assert tot["done"] == 1
         assert (tot["nodes"], tot["cuts"], tot["solutions"]) == (ref["nodes"], ref["cuts"], ref["solutions"])
         assert all(x > 0 for x in tot["lanes"])
-    assert runs[0] == runs[1]
+    # the totals are the tree's; which lane walks which subtree is not fixed: the fused levels (cs_step.hip.h) hand
+    # parents to waves by ticket, so the order of a frontier's survivors in the pool -- and with it the frontier a
+    # lane seeds the others from -- depends on timing
+    for k in ("nodes", "cuts", "solutions", "props", "best", "done"):
+        assert runs[0][k] == runs[1][k], k
     # MIN: the lanes keep ONE incumbent in device memory (share_incumbent), so what a lane prunes depends on when
     # the others find their solutions: the optimum is fixed, the node counts are not
     model = solve_root(problems.schedule(8, 1))

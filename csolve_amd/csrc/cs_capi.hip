@@ -975,7 +975,15 @@ extern "C" int csgpu_internal_step(const csgpu_model *m, const csgpu_step_launch
   const int64_t K = L->stage_rows / waves;
   /* parents per ticket: about eight tickets per wave, at most 32 parents, and a chunk's worst case fits half a region */
   int64_t chunk = (int64_t)L->parents / (waves * 8);
-  if (chunk > 32) chunk = 32;
+  /* one word takes about 88 atomics per microsecond (MI355X_MICROARCH.md): with 32 parents per ticket a queens-16 frontier
+   * of three million parents drew 78 tickets per microsecond and the whole launch waited for them (61 ms per search; 51 ms
+   * with 64 and with 128 per ticket, 181 ms with 8) */
+  int64_t chunk_max = 128;
+  {
+    const char *e = getenv("CSGPU_STEP_CHUNK_MAX"); /* tuning */
+    if (e != NULL && atoi(e) > 0) chunk_max = atoi(e);
+  }
+  if (chunk > chunk_max) chunk = chunk_max;
   if (chunk * maxw > K / 2) chunk = K / (2 * maxw);
   chunk = chunk / G * G;
   if (chunk < G) chunk = G;

@@ -1017,6 +1017,13 @@ extern "C" int csgpu_search_create(const csgpu_model *m, int64_t pool_capacity, 
                !(ev != NULL && ev[0] == '1');
   }
   s->stage_rows = max_children;
+  if (s->fused) {
+    /* twice the rows a frontier's children may have: a wave's region then takes the worst case of a ticket of 64 parents
+     * (fewer parents per ticket and the ticket counter limits the launch, cs_capi.hip) */
+    s->stage_rows = 2 * max_children;
+    const char *e = getenv("CSGPU_STEP_STAGE_MULT"); /* tuning: staging rows per max_children */
+    if (e != NULL && atoi(e) >= 1) s->stage_rows = max_children * atoi(e);
+  }
   s->surv_per_parent = (double)s->max_width;
   if (s->fused) {
     s->fw = 0; /* interval rows only: no sets in the pool, nothing to rebuild for states put from outside */
@@ -1041,7 +1048,7 @@ extern "C" int csgpu_search_create(const csgpu_model *m, int64_t pool_capacity, 
   ALLOC(s->d_block_sum, sizeof(int) * ((size_t)max_children + 1));
   ALLOC(s->d_block_skip, sizeof(int) * ((size_t)max_children + 1));
   ALLOC(s->d_nodes, sizeof(csgpu_node) * (size_t)max_children);
-  ALLOC(s->d_child_states, row * (size_t)max_children);
+  ALLOC(s->d_child_states, row * (size_t)(s->fused ? s->stage_rows : max_children));
   if (!s->fused) ALLOC(s->d_complete_states, row * (size_t)max_children);
   ALLOC(s->d_results, sizeof(csgpu_result) * (size_t)max_children);
   ALLOC(s->d_dest, sizeof(int) * (size_t)max_children);

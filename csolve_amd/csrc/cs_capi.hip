@@ -623,6 +623,7 @@ static const void *ne_packed_kernel(int n_vars, int nw, int s3) {
 
 static const void *step_packed_kernel(int n_vars, int nw, int s3); /* below, with the step launcher */
 static const void *step_import_kernel(int n_vars, int nw, int s3);
+static const void *step_shave_kernel(int width, int n_vars, int slots, int full);
 
 /* kernel 6: clauses per lane (1, 2, 4, 8) if the model has at most 512 clauses, else 0 */
 static int clause_rounds_cpl(const csgpu_model *m) {
@@ -811,6 +812,11 @@ extern "C" int csgpu_model_finalize(csgpu_model *m) {
               return rc;
           for (int full = 0; full < 2; full++)
             if ((rc = lds_limit(bytes, ne_shave_kernel(m->img->dense_width, h->n_vars, m->img->dense_slots, full)))) return rc;
+          if (((bytes + 15) & ~(size_t)15) + (size_t)best_waves * 32 <= 160u * 1024u)
+            for (int full = 0; full < 2; full++)
+              if ((rc = lds_limit(((bytes + 15) & ~(size_t)15) + (size_t)best_waves * 32,
+                                  step_shave_kernel(m->img->dense_width, h->n_vars, m->img->dense_slots, full))))
+                return rc;
           if (((bytes + 15) & ~(size_t)15) + CS_SHAVE_TRACE_LDS * 16 <= 160u * 1024u &&
               (rc = lds_limit(((bytes + 15) & ~(size_t)15) + CS_SHAVE_TRACE_LDS * 16,
                               ne_shave_trace_kernel(m->img->dense_width, h->n_vars, m->img->dense_slots))))
@@ -941,17 +947,120 @@ static size_t step_packed_lds(const csgpu_model *m, int waves) {
   return ((2 * m->dense_bytes + 15) & ~(size_t)15) + (size_t)waves * ((1 + m->packed_nw) * 256 + CS_STEP_QN) * sizeof(unsigned);
 }
 
+static const void *step_shave_kernel(int width, int n_vars, int slots, int full) {
+  const int chunks = (n_vars + CS_WAVE - 1) / CS_WAVE;
+#define CS_PICK_S(E, R)                                                                                   \
+  if (slots == 1) return full ? (const void *)cs_step_shave<E, R, 1, true> : (const void *)cs_step_shave<E, R, 1, false>; \
+  if (slots == 3) return full ? (const void *)cs_step_shave<E, R, 3, true> : (const void *)cs_step_shave<E, R, 3, false>; \
+  return full ? (const void *)cs_step_shave<E, R, 0, true> : (const void *)cs_step_shave<E, R, 0, false>;
+#define CS_PICK(E)                                                                                 \
+  switch (chunks <= 1 ? 1 : (chunks <= 2 ? 2 : 4)) {                                               \
+  case 1: CS_PICK_S(E, 1)                                                                          \
+  case 2: CS_PICK_S(E, 2)                                                                          \
+  default: CS_PICK_S(E, 4)                                                                         \
+  }
+  if (width == 1) { CS_PICK(unsigned char) }
+  CS_PICK(unsigned short)
+#undef CS_PICK
+#undef CS_PICK_S
+}
+
+static int model_max_width(const csgpu_model *m) {
+  int maxw = 2;
+  for (int32_t v = 0; v < m->host->n_vars; v++) {
+    const int64_t w = (int64_t)m->host->dom[v].hi - (int64_t)m->host->dom[v].lo + 1;
+    if (w > maxw) maxw = w > 0x7fffffff ? 0x7fffffff : (int)w;
+  }
+  return maxw;
+}
+
+/* LDS of a cs_step_shave workgroup: the dense table, then eight mask words per wave */
+static size_t step_shave_lds(const csgpu_model *m) {
+  return ((m->dense_bytes + 15) & ~(size_t)15) + (size_t)m->dense_waves * 8 * sizeof(unsigned);
+}
+
 extern "C" int csgpu_internal_step_kind(const csgpu_model *m) {
-  if (m == NULL || !m->finalized || m->img == NULL || m->d_packed_tab == NULL) return 0;
-  if (!(m->dense_waves && packed_nodes_per_wave(m->fb_words, m->host->n_vars, m->img->dense_width))) return 0;
-  if (step_packed_lds(m, 16) > 80u * 1024u) return 0; /* two workgroups of sixteen waves per CU */
-  return 1;
+  if (m == NULL || !m->finalized || m->img == NULL || !m->dense_waves) return 0;
+  if (m->d_packed_tab != NULL && packed_nodes_per_wave(m->fb_words, m->host->n_vars, m->img->dense_width) &&
+      step_packed_lds(m, 16) <= 80u * 1024u) /* two workgroups of sixteen waves per CU */
+    return 1;
+  if (m->host->n_vars <= 256 && model_max_width(m) <= 256 && step_shave_lds(m) <= 160u * 1024u) return 2;
+  return 0;
+}
+
+/* waves of a cs_step_shave launch with `stage_rows` staging rows: the resident grid, fewer when a wave's region would
+ * not hold the children of four parents */
+static int64_t step_shave_waves(const csgpu_model *m, int64_t stage_rows) {
+  size_t wgs = (160u * 1024u) / step_shave_lds(m);
+  if (wgs > (size_t)(32 / m->dense_waves)) wgs = (size_t)(32 / m->dense_waves);
+  int64_t waves = (int64_t)m->n_cus * (int64_t)wgs * m->dense_waves;
+  const int64_t by_stage = stage_rows / (4 * (int64_t)model_max_width(m));
+  if (waves > by_stage) waves = by_stage / m->dense_waves * m->dense_waves;
+  return waves;
+}
+
+extern "C" int64_t csgpu_internal_step_parents_limit(const csgpu_model *m, int64_t stage_rows) {
+  const int kind = csgpu_internal_step_kind(m);
+  if (kind == 1) return 0x3fffffff;
+  if (kind != 2) return 0;
+  const int maxw = model_max_width(m);
+  const int64_t waves = step_shave_waves(m, stage_rows);
+  if (waves < 1) return 0;
+  return (stage_rows - waves * 2 * maxw) / maxw; /* every child of every parent may survive, and a wave stops two parents short of its region's end */
+}
+
+extern "C" int64_t csgpu_internal_step_stage_rows(const csgpu_model *m) {
+  if (csgpu_internal_step_kind(m) != 2) return 0;
+  return (int64_t)m->n_cus * 32 * 4 * model_max_width(m);
 }
 
 extern "C" int64_t csgpu_internal_step_waves(const csgpu_model *m) { return m == NULL ? 0 : (int64_t)m->n_cus * 32; }
 
+static int launch_step_shave(const csgpu_model *m, const csgpu_step_launch *L, void *stream) {
+  const int n = m->host->n_vars, maxw = model_max_width(m);
+  int64_t waves = step_shave_waves(m, L->stage_rows);
+  if (waves < m->dense_waves || (int64_t)L->parents > csgpu_internal_step_parents_limit(m, L->stage_rows))
+    return set_err(CSGPU_E_LIMIT, "step kernel: staging buffer too small for the frontier");
+  const int64_t by_parents = ((int64_t)L->parents + m->dense_waves - 1) / m->dense_waves * m->dense_waves;
+  if (waves > by_parents) waves = by_parents;
+  const int64_t grid = waves / m->dense_waves;
+  const int64_t K = L->stage_rows / waves;
+  cs_step_io io;
+  io.pool = (const uint2 *)L->pool;
+  io.first_row = (long long)L->first_row;
+  io.parents = L->parents;
+  io.chunk = 1;
+  io.maxw = maxw;
+  io.stage = (uint2 *)L->stage;
+  io.K = (int)(K > 0x7fffffff ? 0x7fffffff : K);
+  io.fill = L->fill;
+  io.wstat = (unsigned long long *)L->wstat;
+  io.ticket = L->ticket;
+  io.solutions = L->solutions;
+  io.stored = (unsigned long long *)L->stored;
+  io.max_solutions = (long long)L->max_solutions;
+  io.store_open = L->store_open;
+  int nn = n, slots = m->img->dense_slots, dmin_d = m->img->dense_dmin;
+  const void *tab_d = m->d_dense_tab;
+  const int *root_lo_d = m->d_root_lo, *sym_off = m->d_sym_off;
+  size_t tab_bytes = m->dense_bytes;
+  void *args[] = { &nn, &tab_d, &slots, &dmin_d, &root_lo_d, &sym_off, &tab_bytes, &io };
+  const int chunks_v = (n + CS_WAVE - 1) / CS_WAVE;
+  const int lanes = (chunks_v <= 1 ? 1 : (chunks_v <= 2 ? 2 : 4)) * CS_WAVE;
+  HIP_TRY(hipLaunchKernel(step_shave_kernel(m->img->dense_width, n, slots, n == lanes), dim3((unsigned)grid),
+                          dim3((unsigned)(m->dense_waves * CS_WAVE)), args, step_shave_lds(m), (hipStream_t)stream));
+  hipLaunchKernelGGL(cs_collect, dim3((unsigned)waves), dim3(256), 0, (hipStream_t)stream, (const unsigned *)L->fill, (int)waves,
+                     (const uint2 *)L->stage, io.K, n, (uint2 *)L->pool, (long long)L->first_row, (int)L->parents,
+                     0 /* every parent is drawn */, (const unsigned *)L->ticket, (const unsigned long long *)L->wstat,
+                     (unsigned long long *)L->out, (const unsigned long long *)L->stored);
+  HIP_TRY(hipGetLastError());
+  return CSGPU_OK;
+}
+
 extern "C" int csgpu_internal_step(const csgpu_model *m, const csgpu_step_launch *L, void *stream) {
-  if (csgpu_internal_step_kind(m) != 1 || L == NULL || L->parents < 1) return set_err(CSGPU_E_ARG, "bad argument");
+  const int kind = csgpu_internal_step_kind(m);
+  if (kind == 0 || L == NULL || L->parents < 1) return set_err(CSGPU_E_ARG, "bad argument");
+  if (kind == 2) return launch_step_shave(m, L, stream);
   const int n = m->host->n_vars;
   const int G = n <= 16 ? 4 : 2;
   int maxw = 2;
@@ -1019,6 +1128,7 @@ extern "C" int csgpu_internal_step(const csgpu_model *m, const csgpu_step_launch
 
 extern "C" int csgpu_internal_step_import(const csgpu_model *m, csgpu_val *d_rows, int64_t first_row, int64_t count,
                                           void *stream) {
+  if (csgpu_internal_step_kind(m) == 2) return CSGPU_OK; /* that path's pool holds interval rows */
   if (csgpu_internal_step_kind(m) != 1 || d_rows == NULL || count < 0) return set_err(CSGPU_E_ARG, "bad argument");
   if (count == 0) return CSGPU_OK;
   const int n = m->host->n_vars, G = n <= 16 ? 4 : 2;
@@ -1037,6 +1147,7 @@ extern "C" int csgpu_internal_step_import(const csgpu_model *m, csgpu_val *d_row
 
 extern "C" int csgpu_internal_step_export(const csgpu_model *m, csgpu_val *d_rows, int64_t first_row, int64_t count,
                                           void *stream) {
+  if (csgpu_internal_step_kind(m) == 2) return CSGPU_OK;
   if (csgpu_internal_step_kind(m) != 1 || d_rows == NULL || count < 0) return set_err(CSGPU_E_ARG, "bad argument");
   if (count == 0) return CSGPU_OK;
   const int n = m->host->n_vars;

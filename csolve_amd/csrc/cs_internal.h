@@ -52,8 +52,13 @@ typedef struct csgpu_step_launch {
   int64_t max_solutions;
   int32_t store_open;
 } csgpu_step_launch;
-/* 0: the model has no step kernel; 1: cs_step_packed (pure != network of at most 32 variables) */
+/* 0: the model has no step kernel; 1: cs_step_packed (pure != network of at most 32 variables, engine rows in the pool);
+ * 2: cs_step_shave (33 to 256 variables, plain interval rows) */
 int csgpu_internal_step_kind(const csgpu_model *m);
+/* parents one launch may be given with `stage_rows` staging rows (kind 2 sizes for the worst case: every child survives) */
+int64_t csgpu_internal_step_parents_limit(const csgpu_model *m, int64_t stage_rows);
+/* staging rows that let a launch of kind 2 use the whole machine (0 for the others) */
+int64_t csgpu_internal_step_stage_rows(const csgpu_model *m);
 /* waves of the largest grid a step launch uses (sizes fill / wstat) */
 int64_t csgpu_internal_step_waves(const csgpu_model *m);
 /* the step kernel over the parents, then cs_collect: survivors appended to the pool behind the parents nobody drew,

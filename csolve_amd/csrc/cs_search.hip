@@ -1023,6 +1023,9 @@ extern "C" int csgpu_search_create(const csgpu_model *m, int64_t pool_capacity, 
     s->stage_rows = 2 * max_children;
     const char *e = getenv("CSGPU_STEP_STAGE_MULT"); /* tuning: staging rows per max_children */
     if (e != NULL && atoi(e) >= 1) s->stage_rows = max_children * atoi(e);
+    /* one wave per parent (33 to 256 variables): room for the children of four parents in every wave's region */
+    if (s->stage_rows < csgpu_internal_step_stage_rows(m)) s->stage_rows = csgpu_internal_step_stage_rows(m);
+    if (s->stage_rows > s->cap) s->stage_rows = s->cap;
   }
   s->surv_per_parent = (double)s->max_width;
   if (s->fused) {
@@ -1030,7 +1033,7 @@ extern "C" int csgpu_search_create(const csgpu_model *m, int64_t pool_capacity, 
     const int64_t waves = csgpu_internal_step_waves(m);
     ALLOC(s->d_fill, sizeof(uint32_t) * (size_t)waves);
     ALLOC(s->d_wstat, sizeof(uint64_t) * 8 * (size_t)waves);
-    ALLOC(s->d_ticket, 64);
+    ALLOC(s->d_ticket, 1024); /* sixteen counters on their own 64-byte lines */
     ALLOC(s->d_step_out, sizeof(uint64_t) * 8);
     if ((e = hipHostMalloc((void **)&s->h_step_out, sizeof(uint64_t) * 8, 0)) != hipSuccess) {
       csgpu_search_free(s);
@@ -1333,8 +1336,18 @@ static int one_iteration_fused(csgpu_search *s) {
   L.parents = (int32_t)parents;
   L.stage = (csgpu_val *)s->d_child_states;
   L.stage_rows = s->stage_rows;
-  /* the survivors land behind the undrawn parents: never more than the pool has room for */
-  if (L.stage_rows > s->cap - (s->top - parents)) L.stage_rows = s->cap - (s->top - parents);
+  /* the survivors land behind the undrawn parents: never more than the pool has room for above its top (the rows the
+   * drawn parents free come on top of that) */
+  if (L.stage_rows > s->cap - s->top) L.stage_rows = s->cap - s->top;
+  {
+    const int64_t limit = csgpu_internal_step_parents_limit(s->m, L.stage_rows);
+    if (limit < 1) return fail(CSGPU_E_LIMIT, "state pool is full");
+    if (parents > limit) {
+      parents = limit;
+      L.first_row = s->top - parents;
+      L.parents = (int32_t)parents;
+    }
+  }
   L.fill = s->d_fill;
   L.wstat = s->d_wstat;
   L.ticket = s->d_ticket;
@@ -1343,7 +1356,7 @@ static int one_iteration_fused(csgpu_search *s) {
   L.stored = (uint64_t *)(s->d_counters + C_STORED);
   L.max_solutions = s->max_solutions;
   L.store_open = s->stored_seen < (uint64_t)s->max_solutions;
-  HIP_OK(hipMemsetAsync(s->d_ticket, 0, sizeof(uint32_t), 0));
+  HIP_OK(hipMemsetAsync(s->d_ticket, 0, 1024, 0));
   const int rc = csgpu_internal_step(s->m, &L, NULL);
   if (rc != CSGPU_OK) return rc;
   HIP_OK(hipMemcpyAsync(s->h_step_out, s->d_step_out, sizeof(uint64_t) * 8, hipMemcpyDeviceToHost, 0));

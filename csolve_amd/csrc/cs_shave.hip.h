@@ -95,6 +95,241 @@ __device__ __forceinline__ int cs_writelane_at(int lane, int v, int x) {
 #define CS_SHAVE_SHARDS 64      /* ticket counters per launch at most */
 #define CS_SHAVE_TICKET_STRIDE 16 /* unsigned words between two counters: one 64-byte line each */
 
+/* The fixpoint of ONE node on a wave's registers: PUSH / VERIFY as described at the top of this file.  Shared by
+ * kernel 7 (cs_propagate_ne_shave: a batch of nodes) and by the search's level kernel (cs_step_shave, cs_step.hip.h:
+ * the children of a parent are run from the parent's registers).  Every function is inlined into its caller. */
+template <typename E, int R, int SL, bool TRACE>
+struct cs_shave_core {
+  typedef unsigned long long u64;
+  static constexpr int W = CS_WAVE * R; /* columns of the table */
+  const E *s_tab;
+  int slots, lane;
+  int kb[R], deg[R], b0[R];
+  u64 livemask[R];
+  int4 *s_trace;   /* TRACE: the records of the node, in LDS */
+  unsigned tcount; /* TRACE: records made so far (one wave, one node: a scalar) */
+
+  /* the lanes of `mask` (register r2) record their new bound, moved because of variable `cause` */
+  __device__ __forceinline__ void trace_lanes(u64 mask, int r2, int kind, int value, int cause) {
+    if (mask == 0ull) return;
+    const unsigned at = tcount + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+    /* into LDS: a store to the caller's (host-mapped) buffer would be waited for before the registers are reused,
+     * a PCIe round trip per row operation (measured: 3.4 us per operation, 1 ms for a cascade of 300) */
+    if (__builtin_amdgcn_inverse_ballot_w64(mask) && at < CS_SHAVE_TRACE_LDS) /* (no 64-bit shift by a lane number: tools/k4_fault_repro.md) */
+      s_trace[at] = make_int4(lane + r2 * CS_WAVE, kind, value + b0[r2], cause);
+    tcount += (unsigned)__builtin_popcountll(mask);
+  }
+
+  /* PUSH(u): the variable `ul` of register r is the value cd + dmin; every lane moves a bound that equals the
+   * value u forbids for it by one and is dirty then */
+  __device__ __forceinline__ void push_var(int r, int ul, int cd, int (&rlo)[R], int (&rhi)[R], u64 (&dl)[R], u64 (&dh)[R],
+                                           int &revisions) {
+    revisions += __builtin_amdgcn_readlane(deg[r], ul);
+    const E *row = s_tab + (size_t)(ul + r * CS_WAVE) * slots * W + lane;
+    /* The slots are applied one after the other to the bounds as they stand (a bound moved by slot k may be moved
+     * again by slot k + 1: both values are forbidden by u, each move is one narrowing); `bound += (f == bound)` is
+     * a compare into VCC and an add with carry-in, and which bounds moved is ONE compare per bound at the end --
+     * the scalar unit merges nothing. */
+    int plo[R], phi[R];
+#pragma unroll
+    for (int r2 = 0; r2 < R; r2++) { plo[r2] = rlo[r2]; phi[r2] = rhi[r2]; }
+    if (SL != 0) {
+#pragma unroll
+      for (int k = 0; k < (SL ? SL : 1); k++) {
+#pragma unroll
+        for (int r2 = 0; r2 < R; r2++) {
+          const int f = cd - (int)row[k * W + r2 * CS_WAVE]; /* the value of w that u forbids (sentinel: < 0) */
+          rlo[r2] = cs_inc_if_eq(rlo[r2], f);
+          rhi[r2] = cs_dec_if_eq(rhi[r2], f);
+        }
+      }
+    } else {
+      for (int k = 0; k < slots; k++) {
+#pragma unroll
+        for (int r2 = 0; r2 < R; r2++) {
+          const int f = cd - (int)row[k * W + r2 * CS_WAVE];
+          rlo[r2] = cs_inc_if_eq(rlo[r2], f);
+          rhi[r2] = cs_dec_if_eq(rhi[r2], f);
+        }
+      }
+    }
+#pragma unroll
+    for (int r2 = 0; r2 < R; r2++) {
+      const u64 ml = __ballot(rlo[r2] != plo[r2]), mh = __ballot(rhi[r2] != phi[r2]);
+      dl[r2] |= ml;
+      dh[r2] |= mh;
+      if (TRACE) {
+        trace_lanes(ml, r2, 0, rlo[r2], ul + r * CS_WAVE);
+        trace_lanes(mh, r2, 1, rhi[r2], ul + r * CS_WAVE);
+      }
+    }
+  }
+
+  /* the valued variables after a push phase; -1, or a variable whose bounds have crossed */
+  __device__ __forceinline__ int settle(const int (&rlo)[R], const int (&rhi)[R], u64 (&val)[R]) const {
+    int bad = -1;
+#pragma unroll
+    for (int r = R - 1; r >= 0; r--) {
+      const u64 c = __ballot(rlo[r] > rhi[r]);
+      if (c != 0ull) bad = __builtin_ctzll(c) + r * CS_WAVE;
+      val[r] = __ballot(rlo[r] == rhi[r]) & livemask[r];
+    }
+    return bad;
+  }
+
+  /* the fixpoint; returns -1, or a variable whose domain has become empty (what the reference's
+   * propagate_term_confl would be called for, propagate.c:33-41).  push: the variables that push first; pushed: those
+   * that have pushed already; dl / dh: bounds to be verified; val: the variables that are single values now. */
+  __device__ __forceinline__ int fixpoint(int (&rlo)[R], int (&rhi)[R], u64 (&pushed)[R], u64 (&push)[R], u64 (&dl)[R],
+                                          u64 (&dh)[R], u64 (&val)[R], int &rounds, int &revisions) {
+    int fail_v = -1;
+    for (;;) {
+      /* (1) PUSH: every newly valued variable moves the bounds it sits on.  A valued variable's bounds do
+       * not change any more, so "value - dmin" of every pusher of this round is taken from one register. */
+      int cdv[R];
+#pragma unroll
+      for (int r = 0; r < R; r++) cdv[r] = rlo[r] + kb[r];
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        u64 bits = push[r];
+        pushed[r] |= bits;
+        while (bits != 0ull) {
+          const int ul = __builtin_ctzll(bits);
+          bits = cs_bitset0(bits, ul);
+          push_var(r, ul, __builtin_amdgcn_readlane(cdv[r], ul), rlo, rhi, dl, dh, revisions);
+        }
+      }
+      fail_v = settle(rlo, rhi, val);
+      if (fail_v >= 0) return fail_v;
+      /* (2a) Many moved bounds, few valued variables (an assignment on a bound of the root domains moves a bound
+       * of every other queen): cheaper than verifying each moved bound against all valued variables is to let
+       * every valued variable push again -- each sweep moves the bounds that are still forbidden by one more
+       * value -- until the moved bounds are fewer than the valued variables. */
+      for (;;) {
+        int n_dirty = 0, n_val = 0;
+#pragma unroll
+        for (int r = 0; r < R; r++) { n_dirty += __popcll(dl[r] | dh[r]); n_val += __popcll(val[r]); }
+        if (n_dirty <= n_val) break;
+#pragma unroll
+        for (int r = 0; r < R; r++) { cdv[r] = rlo[r] + kb[r]; dl[r] = 0ull; dh[r] = 0ull; }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          u64 bits = val[r];
+          pushed[r] |= bits;
+          while (bits != 0ull) {
+            const int ul = __builtin_ctzll(bits);
+            bits = cs_bitset0(bits, ul);
+            push_var(r, ul, __builtin_amdgcn_readlane(cdv[r], ul), rlo, rhi, dl, dh, revisions);
+          }
+        }
+        fail_v = settle(rlo, rhi, val);
+        if (fail_v >= 0) return fail_v;
+      }
+      /* (2) VERIFY: a moved bound stops at the first value no valued variable forbids.  Lane u holds the
+       * table entry e of (w, k, u); its own value forbids the value rlo[u] + e - kb[w] of w, i.e. the
+       * candidate c is forbidden iff e == c + kb[w] - rlo[u]: one subtraction per register, the compares run
+       * on the raw table bytes.  Mostly the candidate is supported and nothing is written. */
+#pragma unroll
+      for (int side = 0; side < 2; side++) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          u64 bits = side == 0 ? dl[r] : dh[r];
+          if (side == 0) dl[r] = 0ull; else dh[r] = 0ull;
+          while (bits != 0ull) {
+            const int wl = __builtin_ctzll(bits);
+            bits = cs_bitset0(bits, wl);
+            int cand = __builtin_amdgcn_readlane(side == 0 ? rlo[r] : rhi[r], wl);
+            const int ckw = cand + __builtin_amdgcn_readlane(kb[r], wl);
+            revisions += __builtin_amdgcn_readlane(deg[r], wl);
+            const E *row = s_tab + (size_t)(wl + r * CS_WAVE) * slots * W + lane;
+            u64 hit = 0ull;
+            if (SL != 0) {
+              int e[SL ? SL : 1][R];
+#pragma unroll
+              for (int k = 0; k < (SL ? SL : 1); k++)
+#pragma unroll
+                for (int r2 = 0; r2 < R; r2++) e[k][r2] = (int)row[k * W + r2 * CS_WAVE];
+              int cause = -1; /* TRACE: a valued variable that forbids the candidate */
+#pragma unroll
+              for (int r2 = 0; r2 < R; r2++) {
+                const int t = ckw - rlo[r2];
+                u64 h = 0ull;
+#pragma unroll
+                for (int k = 0; k < (SL ? SL : 1); k++) h |= __ballot(e[k][r2] == t);
+                hit |= h & val[r2];
+                if (TRACE && cause < 0 && (h & val[r2]) != 0ull) cause = __builtin_ctzll(h & val[r2]) + r2 * CS_WAVE;
+              }
+              if (hit == 0ull) continue; /* supported: the common case */
+              /* the bound moves on, one value (one PROPS) at a time, until it is supported or passes the other */
+              const int other = __builtin_amdgcn_readlane(side == 0 ? rhi[r] : rlo[r], wl);
+              int step = 0;
+              for (;;) {
+                step++;
+                if (side == 0 ? cand + step > other : cand - step < other) break;
+                hit = 0ull;
+#pragma unroll
+                for (int r2 = 0; r2 < R; r2++) {
+                  const int t = ckw + (side == 0 ? step : -step) - rlo[r2];
+                  u64 h = 0ull;
+#pragma unroll
+                  for (int k = 0; k < (SL ? SL : 1); k++) h |= __ballot(e[k][r2] == t);
+                  hit |= h & val[r2];
+                }
+                if (hit == 0ull) break;
+              }
+              cand += side == 0 ? step : -step;
+              if (lane == wl) { if (side == 0) rlo[r] = cand; else rhi[r] = cand; }
+              if (TRACE) trace_lanes(1ull << wl, r, side, cand, cause);
+              /* a bound that passed the other one is the failure: noticed after the loops (no exit from in here) */
+              if (side == 0 ? cand > other : cand < other) fail_v = wl + r * CS_WAVE;
+              if (cand == other) val[r] |= 1ull << wl; /* counts for the verifications that follow */
+            } else {
+              /* run-time slot count: the row is re-read per candidate */
+              const int other = __builtin_amdgcn_readlane(side == 0 ? rhi[r] : rlo[r], wl);
+              int step = 0;
+              int cause = -1;
+              for (;;) {
+                hit = 0ull;
+                for (int k = 0; k < slots; k++) {
+#pragma unroll
+                  for (int r2 = 0; r2 < R; r2++) {
+                    const u64 h = __ballot((int)row[k * W + r2 * CS_WAVE] == ckw + (side == 0 ? step : -step) - rlo[r2]) & val[r2];
+                    hit |= h;
+                    if (TRACE && cause < 0 && h != 0ull) cause = __builtin_ctzll(h) + r2 * CS_WAVE;
+                  }
+                }
+                if (hit == 0ull) break;
+                step++;
+                if (side == 0 ? cand + step > other : cand - step < other) break;
+              }
+              if (step != 0) {
+                cand += side == 0 ? step : -step;
+                if (lane == wl) { if (side == 0) rlo[r] = cand; else rhi[r] = cand; }
+                if (TRACE) trace_lanes(1ull << wl, r, side, cand, cause);
+                if (side == 0 ? cand > other : cand < other) fail_v = wl + r * CS_WAVE;
+                if (cand == other) val[r] |= 1ull << wl;
+              }
+            }
+          }
+        }
+      }
+      if (fail_v >= 0) return fail_v;
+      /* (3) variables that became values (and are supported) push next */
+      u64 any_push = 0ull;
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        push[r] = val[r] & ~pushed[r];
+        any_push |= push[r];
+      }
+      if (any_push == 0ull) return -1;
+      /* a node that goes on cascading is a candidate for the tail of the launch (a few nodes cost 50 times the
+       * average): from its second round on its wave is served first by the SIMD's arbiter */
+      if (rounds == 0) __builtin_amdgcn_s_setprio(3);
+      rounds++;
+    }
+  }
+};
+
 /* SL: slots per pair known at compile time (1 = alldiff-style, 3 = queens), 0 = run-time loop.
  * FULL: n == 64 R, every lane register holds a variable: loads and stores are unconditional. */
 /* TRACE (single-node launches only, csgpu_propagate_one_causes): every bound move is recorded as
@@ -160,6 +395,10 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_shave(
   u64 livemask[R]; /* lanes that hold a variable: the others look like values and must never push or forbid */
 #pragma unroll
   for (int r = 0; r < R; r++) livemask[r] = FULL ? ~0ull : __ballot(live[r]);
+  cs_shave_core<E, R, SL, TRACE> C;
+  C.s_tab = s_tab; C.slots = slots; C.lane = lane; C.s_trace = s_trace; C.tcount = 0u;
+#pragma unroll
+  for (int r = 0; r < R; r++) { C.kb[r] = kb[r]; C.deg[r] = deg[r]; C.b0[r] = b0[r]; C.livemask[r] = livemask[r]; }
   unsigned *my_ticket = tickets + (size_t)shard * CS_SHAVE_TICKET_STRIDE;
 
   /* the record of chunk i of this shard (lanes 0 .. csz-1); lanes past the end of the batch hold a no-op */
@@ -265,227 +504,14 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_shave(
         push[r] = val[r] & ~pushed[r];
       }
 
-      unsigned tcount = 0u; /* TRACE: records made so far (one wave, one node: a scalar) */
-      /* the lanes of `mask` (register r2) record their new bound, moved because of variable `cause` */
-      auto trace_lanes = [&](u64 mask, int r2, int kind, int value, int cause) {
-        if (mask == 0ull) return;
-        const unsigned at = tcount + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-        /* into LDS: a store to the caller's (host-mapped) buffer would be waited for before the registers are reused,
-         * a PCIe round trip per row operation (measured: 3.4 us per operation, 1 ms for a cascade of 300) */
-        if (__builtin_amdgcn_inverse_ballot_w64(mask) && at < CS_SHAVE_TRACE_LDS) /* (no 64-bit shift by a lane number: tools/k4_fault_repro.md) */
-          s_trace[at] = make_int4(lane + r2 * CS_WAVE, kind, value + b0[r2], cause);
-        tcount += (unsigned)__builtin_popcountll(mask);
-      };
+      C.tcount = 0u;
       int rounds = 0, revisions = 0;
-      /* PUSH(u): the variable `ul` of register r is the value cd + dmin; every lane moves a bound that equals the
-       * value u forbids for it by one and is dirty then */
-      auto push_var = [&](int r, int ul, int cd) {
-        revisions += __builtin_amdgcn_readlane(deg[r], ul);
-        const E *row = s_tab + (size_t)(ul + r * CS_WAVE) * slots * W + lane;
-        /* The slots are applied one after the other to the bounds as they stand (a bound moved by slot k may be moved
-         * again by slot k + 1: both values are forbidden by u, each move is one narrowing); `bound += (f == bound)` is
-         * a compare into VCC and an add with carry-in, and which bounds moved is ONE compare per bound at the end --
-         * the scalar unit merges nothing. */
-        int plo[R], phi[R];
-#pragma unroll
-        for (int r2 = 0; r2 < R; r2++) { plo[r2] = rlo[r2]; phi[r2] = rhi[r2]; }
-        if (SL != 0) {
-#pragma unroll
-          for (int k = 0; k < (SL ? SL : 1); k++) {
-#pragma unroll
-            for (int r2 = 0; r2 < R; r2++) {
-              const int f = cd - (int)row[k * W + r2 * CS_WAVE]; /* the value of w that u forbids (sentinel: < 0) */
-              rlo[r2] = cs_inc_if_eq(rlo[r2], f);
-              rhi[r2] = cs_dec_if_eq(rhi[r2], f);
-            }
-          }
-        } else {
-          for (int k = 0; k < slots; k++) {
-#pragma unroll
-            for (int r2 = 0; r2 < R; r2++) {
-              const int f = cd - (int)row[k * W + r2 * CS_WAVE];
-              rlo[r2] = cs_inc_if_eq(rlo[r2], f);
-              rhi[r2] = cs_dec_if_eq(rhi[r2], f);
-            }
-          }
-        }
-#pragma unroll
-        for (int r2 = 0; r2 < R; r2++) {
-          const u64 ml = __ballot(rlo[r2] != plo[r2]), mh = __ballot(rhi[r2] != phi[r2]);
-          dl[r2] |= ml;
-          dh[r2] |= mh;
-          if (TRACE) {
-            trace_lanes(ml, r2, 0, rlo[r2], ul + r * CS_WAVE);
-            trace_lanes(mh, r2, 1, rhi[r2], ul + r * CS_WAVE);
-          }
-        }
-      };
-      /* the fixpoint; returns -1, or a variable whose domain has become empty (what the reference's
-       * propagate_term_confl would be called for, propagate.c:33-41) */
-      /* the valued variables after a push phase; -1, or a variable whose bounds have crossed */
-      auto settle = [&]() -> int {
-        int bad = -1;
-#pragma unroll
-        for (int r = R - 1; r >= 0; r--) {
-          const u64 c = __ballot(rlo[r] > rhi[r]);
-          if (c != 0ull) bad = __builtin_ctzll(c) + r * CS_WAVE;
-          val[r] = __ballot(rlo[r] == rhi[r]) & livemask[r];
-        }
-        return bad;
-      };
-      auto fixpoint = [&]() -> int {
-        int fail_v = -1;
-        for (;;) {
-          /* (1) PUSH: every newly valued variable moves the bounds it sits on.  A valued variable's bounds do
-           * not change any more, so "value - dmin" of every pusher of this round is taken from one register. */
-          int cdv[R];
-#pragma unroll
-          for (int r = 0; r < R; r++) cdv[r] = rlo[r] + kb[r];
-#pragma unroll
-          for (int r = 0; r < R; r++) {
-            u64 bits = push[r];
-            pushed[r] |= bits;
-            while (bits != 0ull) {
-              const int ul = __builtin_ctzll(bits);
-              bits = cs_bitset0(bits, ul);
-              push_var(r, ul, __builtin_amdgcn_readlane(cdv[r], ul));
-            }
-          }
-          fail_v = settle();
-          if (fail_v >= 0) return fail_v;
-          /* (2a) Many moved bounds, few valued variables (an assignment on a bound of the root domains moves a bound
-           * of every other queen): cheaper than verifying each moved bound against all valued variables is to let
-           * every valued variable push again -- each sweep moves the bounds that are still forbidden by one more
-           * value -- until the moved bounds are fewer than the valued variables. */
-          for (;;) {
-            int n_dirty = 0, n_val = 0;
-#pragma unroll
-            for (int r = 0; r < R; r++) { n_dirty += __popcll(dl[r] | dh[r]); n_val += __popcll(val[r]); }
-            if (n_dirty <= n_val) break;
-#pragma unroll
-            for (int r = 0; r < R; r++) { cdv[r] = rlo[r] + kb[r]; dl[r] = 0ull; dh[r] = 0ull; }
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-              u64 bits = val[r];
-              pushed[r] |= bits;
-              while (bits != 0ull) {
-                const int ul = __builtin_ctzll(bits);
-                bits = cs_bitset0(bits, ul);
-                push_var(r, ul, __builtin_amdgcn_readlane(cdv[r], ul));
-              }
-            }
-            fail_v = settle();
-            if (fail_v >= 0) return fail_v;
-          }
-          /* (2) VERIFY: a moved bound stops at the first value no valued variable forbids.  Lane u holds the
-           * table entry e of (w, k, u); its own value forbids the value rlo[u] + e - kb[w] of w, i.e. the
-           * candidate c is forbidden iff e == c + kb[w] - rlo[u]: one subtraction per register, the compares run
-           * on the raw table bytes.  Mostly the candidate is supported and nothing is written. */
-#pragma unroll
-          for (int side = 0; side < 2; side++) {
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-              u64 bits = side == 0 ? dl[r] : dh[r];
-              if (side == 0) dl[r] = 0ull; else dh[r] = 0ull;
-              while (bits != 0ull) {
-                const int wl = __builtin_ctzll(bits);
-                bits = cs_bitset0(bits, wl);
-                int cand = __builtin_amdgcn_readlane(side == 0 ? rlo[r] : rhi[r], wl);
-                const int ckw = cand + __builtin_amdgcn_readlane(kb[r], wl);
-                revisions += __builtin_amdgcn_readlane(deg[r], wl);
-                const E *row = s_tab + (size_t)(wl + r * CS_WAVE) * slots * W + lane;
-                u64 hit = 0ull;
-                if (SL != 0) {
-                  int e[SL ? SL : 1][R];
-#pragma unroll
-                  for (int k = 0; k < (SL ? SL : 1); k++)
-#pragma unroll
-                    for (int r2 = 0; r2 < R; r2++) e[k][r2] = (int)row[k * W + r2 * CS_WAVE];
-                  int cause = -1; /* TRACE: a valued variable that forbids the candidate */
-#pragma unroll
-                  for (int r2 = 0; r2 < R; r2++) {
-                    const int t = ckw - rlo[r2];
-                    u64 h = 0ull;
-#pragma unroll
-                    for (int k = 0; k < (SL ? SL : 1); k++) h |= __ballot(e[k][r2] == t);
-                    hit |= h & val[r2];
-                    if (TRACE && cause < 0 && (h & val[r2]) != 0ull) cause = __builtin_ctzll(h & val[r2]) + r2 * CS_WAVE;
-                  }
-                  if (hit == 0ull) continue; /* supported: the common case */
-                  /* the bound moves on, one value (one PROPS) at a time, until it is supported or passes the other */
-                  const int other = __builtin_amdgcn_readlane(side == 0 ? rhi[r] : rlo[r], wl);
-                  int step = 0;
-                  for (;;) {
-                    step++;
-                    if (side == 0 ? cand + step > other : cand - step < other) break;
-                    hit = 0ull;
-#pragma unroll
-                    for (int r2 = 0; r2 < R; r2++) {
-                      const int t = ckw + (side == 0 ? step : -step) - rlo[r2];
-                      u64 h = 0ull;
-#pragma unroll
-                      for (int k = 0; k < (SL ? SL : 1); k++) h |= __ballot(e[k][r2] == t);
-                      hit |= h & val[r2];
-                    }
-                    if (hit == 0ull) break;
-                  }
-                  cand += side == 0 ? step : -step;
-                  if (lane == wl) { if (side == 0) rlo[r] = cand; else rhi[r] = cand; }
-                  if (TRACE) trace_lanes(1ull << wl, r, side, cand, cause);
-                  /* a bound that passed the other one is the failure: noticed after the loops (no exit from in here) */
-                  if (side == 0 ? cand > other : cand < other) fail_v = wl + r * CS_WAVE;
-                  if (cand == other) val[r] |= 1ull << wl; /* counts for the verifications that follow */
-                } else {
-                  /* run-time slot count: the row is re-read per candidate */
-                  const int other = __builtin_amdgcn_readlane(side == 0 ? rhi[r] : rlo[r], wl);
-                  int step = 0;
-                  int cause = -1;
-                  for (;;) {
-                    hit = 0ull;
-                    for (int k = 0; k < slots; k++) {
-#pragma unroll
-                      for (int r2 = 0; r2 < R; r2++) {
-                        const u64 h = __ballot((int)row[k * W + r2 * CS_WAVE] == ckw + (side == 0 ? step : -step) - rlo[r2]) & val[r2];
-                        hit |= h;
-                        if (TRACE && cause < 0 && h != 0ull) cause = __builtin_ctzll(h) + r2 * CS_WAVE;
-                      }
-                    }
-                    if (hit == 0ull) break;
-                    step++;
-                    if (side == 0 ? cand + step > other : cand - step < other) break;
-                  }
-                  if (step != 0) {
-                    cand += side == 0 ? step : -step;
-                    if (lane == wl) { if (side == 0) rlo[r] = cand; else rhi[r] = cand; }
-                    if (TRACE) trace_lanes(1ull << wl, r, side, cand, cause);
-                    if (side == 0 ? cand > other : cand < other) fail_v = wl + r * CS_WAVE;
-                    if (cand == other) val[r] |= 1ull << wl;
-                  }
-                }
-              }
-            }
-          }
-          if (fail_v >= 0) return fail_v;
-          /* (3) variables that became values (and are supported) push next */
-          u64 any_push = 0ull;
-#pragma unroll
-          for (int r = 0; r < R; r++) {
-            push[r] = val[r] & ~pushed[r];
-            any_push |= push[r];
-          }
-          if (any_push == 0ull) return -1;
-          /* a node that goes on cascading is a candidate for the tail of the launch (a few nodes cost 50 times the
-           * average): from its second round on its wave is served first by the SIMD's arbiter */
-          if (rounds == 0) __builtin_amdgcn_s_setprio(3);
-          rounds++;
-        }
-      };
-      const int fail_var = fixpoint();
+      const int fail_var = C.fixpoint(rlo, rhi, pushed, push, dl, dh, val, rounds, revisions);
       const int failed = fail_var >= 0;
       if (TRACE) { /* the records leave LDS in one coalesced burst; a count beyond CS_SHAVE_TRACE_LDS tells the caller that only that many were kept */
-        const unsigned keep = tcount < CS_SHAVE_TRACE_LDS ? tcount : CS_SHAVE_TRACE_LDS;
+        const unsigned keep = C.tcount < CS_SHAVE_TRACE_LDS ? C.tcount : CS_SHAVE_TRACE_LDS;
         for (unsigned i = lane; i < keep && i < trace_cap; i += CS_WAVE) trace[i] = s_trace[i];
-        if (lane == 0) *trace_n = tcount;
+        if (lane == 0) *trace_n = C.tcount;
       }
       if (rounds != 0) __builtin_amdgcn_s_setprio(0);
 

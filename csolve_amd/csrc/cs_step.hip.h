@@ -41,8 +41,10 @@
 #define CS_STEP_HIP_H
 
 #include "cs_kernels.hip.h"
+#include "cs_shave.hip.h"
 
 #define CS_STEP_QN 256      /* child descriptors a wave can hold (power of two) */
+#define CS_STEP_SHARDS 16   /* ticket counters of cs_step_shave (one parent per ticket) */
 #define CS_STEP_STATS 8     /* words per wave in wstat: nodes, cuts, props, revisions, solutions, parents, 0, 0 */
 
 struct cs_step_io {
@@ -55,7 +57,8 @@ struct cs_step_io {
   int K;
   unsigned *fill;            /* [waves] rows wave w has written */
   unsigned long long *wstat; /* [waves][CS_STEP_STATS] */
-  unsigned *ticket;          /* zero at launch; left at the number of tickets drawn */
+  unsigned *ticket;          /* zero at launch; left at the number of tickets drawn (cs_step_shave: CS_STEP_SHARDS counters,
+                              * one per 64-byte line) */
   int32_t *solutions;        /* [max_solutions][n] */
   unsigned long long *stored;
   long long max_solutions;
@@ -456,6 +459,230 @@ __global__ __launch_bounds__(256) void cs_step_export(int n, const int *__restri
   ((cs_val *)rows)[i] = cs_interval(b0 + rl, b0 + rh);
 }
 
+/* minimum over the wave, in a scalar */
+__device__ __forceinline__ unsigned cs_wave_min_u32(unsigned x) {
+  unsigned y;
+  y = (unsigned)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)x, 0x111, 0xf, 0xf, false); x = y < x ? y : x; /* row_shr:1 */
+  y = (unsigned)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)x, 0x112, 0xf, 0xf, false); x = y < x ? y : x;
+  y = (unsigned)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)x, 0x114, 0xf, 0xf, false); x = y < x ? y : x;
+  y = (unsigned)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)x, 0x118, 0xf, 0xf, false); x = y < x ? y : x; /* lane 15 of a row = row minimum */
+  y = (unsigned)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)x, 0x142, 0xa, 0xf, false); x = y < x ? y : x; /* row_bcast:15 into rows 1 and 3 */
+  y = (unsigned)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)x, 0x143, 0xc, 0xf, false); x = y < x ? y : x; /* row_bcast:31 into rows 2 and 3 */
+  return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
+}
+
+/* cs_step_shave<E, R, SL, FULL>: the same level step for models of 33 to 256 variables, on kernel 7's terms
+ * (cs_shave.hip.h): one wave per parent, lane l holds variables l, l + 64, ...; the pool holds plain interval rows.
+ * A parent is loaded once; its branching variable is the wave minimum of (width - 1, index); the values of its
+ * interval that a valued neighbour forbids are found with ONE row of the table -- lane u holds tab[x][k][u] and knows
+ * which value of x its own value forbids, the lanes OR those bits into eight words of LDS -- and every other value
+ * is a child whose fixpoint (PUSH / VERIFY from the assignment) runs from the parent's registers.
+ * One parent per ticket, CS_STEP_SHARDS ticket counters (parent p belongs to shard p mod CS_STEP_SHARDS; a wave
+ * starts at its own shard and goes on to the others when it is dry).  The caller sizes the frontier for the worst
+ * case (every child survives), so every parent is drawn: a wave that has no room for another parent's children
+ * stops, the others take over. */
+template <typename E, int R, int SL, bool FULL>
+__global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_step_shave(int n, const E *__restrict__ tab_g, int slots, int dmin,
+                                                                        const int *__restrict__ root_lo,
+                                                                        const int *__restrict__ sym_off, size_t tab_bytes,
+                                                                        cs_step_io io) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
+  typedef unsigned long long u64;
+  const int lane = threadIdx.x & (CS_WAVE - 1);
+  const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int waves_per_block = blockDim.x >> 6;
+  const int wave_global = (int)blockIdx.x * waves_per_block + wave_in_block;
+  if (SL != 0) slots = SL;
+  {
+    const int vecs = (int)(tab_bytes / 16);
+    const uint4 *src = (const uint4 *)tab_g;
+    uint4 *dst = (uint4 *)cs_lds;
+    for (int i = threadIdx.x; i < vecs; i += blockDim.x) dst[i] = src[i];
+  }
+  unsigned *s_mask = (unsigned *)(cs_lds + ((tab_bytes + 15) & ~(size_t)15)) + (size_t)wave_in_block * 8;
+  __syncthreads();
+  const cs_val *pool = (const cs_val *)io.pool;
+  cs_val *stage = (cs_val *)io.stage;
+
+  cs_shave_core<E, R, SL, false> C;
+  C.s_tab = (const E *)cs_lds; C.slots = slots; C.lane = lane; C.s_trace = nullptr; C.tcount = 0u;
+  int b0[R], vcl[R];
+  bool live[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const int v = lane + r * CS_WAVE;
+    live[r] = FULL || v < n;
+    vcl[r] = live[r] ? v : n - 1; /* lanes past the end re-read the last variable and ignore it */
+    b0[r] = live[r] ? root_lo[vcl[r]] : 0;
+    C.b0[r] = b0[r];
+    C.kb[r] = b0[r] - dmin;
+    C.deg[r] = live[r] ? sym_off[vcl[r] + 1] - sym_off[vcl[r]] : 0;
+    C.livemask[r] = FULL ? ~0ull : __ballot(live[r]);
+  }
+  constexpr int W = CS_WAVE * R;
+
+  int fill = 0, store_open = io.store_open;
+  int acc_nodes = 0, acc_cuts = 0, acc_sol = 0, acc_parents = 0, acc_revs = 0; /* scalars */
+  int acc_props = 0;                                                           /* per lane */
+  const size_t region = (size_t)wave_global * (size_t)io.K;
+  int shard = wave_global % CS_STEP_SHARDS, tried = 0;
+
+  /* OUT = the next parent (ticket order) of the wave's current shard, or -1 when every shard is dry (a macro: a lambda
+   * that changes captured scalars leaves them in scratch memory) */
+#define CS_STEP_DRAW(OUT)                                                                                            \
+  do {                                                                                                               \
+    (OUT) = -1;                                                                                                      \
+    while (tried < CS_STEP_SHARDS) {                                                                                 \
+      const int count_s_ = (io.parents - shard + CS_STEP_SHARDS - 1) / CS_STEP_SHARDS;                               \
+      unsigned t_ = 0u;                                                                                              \
+      if (count_s_ > 0) {                                                                                            \
+        if (lane == 0) t_ = __hip_atomic_fetch_add(io.ticket + shard * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+        t_ = (unsigned)__builtin_amdgcn_readfirstlane((int)t_);                                                      \
+      }                                                                                                              \
+      if (count_s_ > 0 && t_ < (unsigned)count_s_) { (OUT) = (int)t_ * CS_STEP_SHARDS + shard; break; }              \
+      shard = (shard + 1) % CS_STEP_SHARDS;                                                                          \
+      tried++;                                                                                                       \
+    }                                                                                                                \
+  } while (0)
+  auto load_parent = [&](int p, cs_val *pd) {
+    const size_t prow = (size_t)(io.first_row + (long long)io.parents - 1 - (long long)p) * n;
+#pragma unroll
+    for (int r = 0; r < R; r++) pd[r] = pool[prow + vcl[r]];
+  };
+
+  int p_cur = -1;
+  if (io.maxw <= io.K) CS_STEP_DRAW(p_cur);
+  cs_val pd[R];
+  if (p_cur >= 0) load_parent(p_cur, pd);
+  while (p_cur >= 0) {
+    p_cur = __builtin_amdgcn_readfirstlane(p_cur);
+    fill = __builtin_amdgcn_readfirstlane(fill);
+    shard = __builtin_amdgcn_readfirstlane(shard);
+    tried = __builtin_amdgcn_readfirstlane(tried);
+    store_open = __builtin_amdgcn_readfirstlane(store_open);
+    /* the parent in registers (relative to the root lower bounds), the next one's ticket and row on their way */
+    int plo[R], phi[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      plo[r] = live[r] ? pd[r].lo - b0[r] : 0;
+      phi[r] = live[r] ? pd[r].hi - b0[r] : 0;
+    }
+    acc_parents++;
+    /* room for one more parent's children behind this one's (worst case both)? */
+    int p_next = -1;
+    if (fill + 2 * io.maxw <= io.K) CS_STEP_DRAW(p_next);
+    if (p_next >= 0) load_parent(p_next, pd);
+    u64 pval[R];
+    unsigned key = 0xffffffffu;
+#pragma unroll
+    for (int r = R - 1; r >= 0; r--) {
+      pval[r] = __ballot(plo[r] == phi[r]) & C.livemask[r];
+      const bool open = live[r] && plo[r] != phi[r];
+      const unsigned k = ((unsigned)(phi[r] - plo[r]) << 8) | (unsigned)(lane + r * CS_WAVE);
+      key = open && k < key ? k : key;
+    }
+    const unsigned kmin = cs_wave_min_u32(key);
+    if (kmin != 0xffffffffu) { /* (a pool row always has an open variable) */
+      const int bv = (int)(kmin & 0xffu), br = bv >> 6, bl = bv & 63;
+      int blo = 0, bhi = 0, kbw = 0;
+#pragma unroll
+      for (int r = 0; r < R; r++)
+        if (r == br) {
+          blo = __builtin_amdgcn_readlane(plo[r], bl);
+          bhi = __builtin_amdgcn_readlane(phi[r], bl);
+          kbw = __builtin_amdgcn_readlane(C.kb[r], bl);
+        }
+      const int width = bhi - blo + 1;
+      /* holes: lane u's own value forbids the value e + plo[u] - kb[x] of x (cs_shave.hip.h, VERIFY) */
+      if (lane < 8) s_mask[lane] = 0u;
+      {
+        const E *row = (const E *)cs_lds + (size_t)bv * slots * W + lane;
+        for (int k = 0; k < slots; k++) {
+#pragma unroll
+          for (int r2 = 0; r2 < R; r2++) {
+            const int c = (int)row[k * W + r2 * CS_WAVE] + plo[r2] - kbw - blo;
+            if (__builtin_amdgcn_inverse_ballot_w64(pval[r2]) && c >= 0 && c < width) atomicOr(&s_mask[c >> 5], 1u << (c & 31));
+          }
+        }
+      }
+      acc_nodes += width;
+      /* the children: every value of [blo, bhi] whose bit is clear */
+      for (int wd = 0; wd * 32 < width; wd++) {
+        unsigned m = (unsigned)__builtin_amdgcn_readfirstlane((int)s_mask[wd]);
+        const int bits = width - wd * 32 < 32 ? width - wd * 32 : 32;
+        unsigned todo = ~m & (bits == 32 ? 0xffffffffu : (1u << bits) - 1u);
+        acc_cuts += bits - __builtin_popcount(todo);
+        while (todo != 0u) {
+          const int j = __builtin_ctz(todo);
+          todo &= todo - 1u;
+          const int value = blo + wd * 32 + j;
+          int rlo[R], rhi[R], lo0[R], hi0[R];
+          u64 pushed[R], push[R], dl[R], dh[R], val[R];
+#pragma unroll
+          for (int r = 0; r < R; r++) {
+            rlo[r] = plo[r]; rhi[r] = phi[r];
+            pushed[r] = pval[r] | ~C.livemask[r]; /* lanes without a variable look like values: they never push */
+            push[r] = 0ull; dl[r] = 0ull; dh[r] = 0ull;
+            val[r] = pval[r];
+            if (r == br) {
+              if (lane == bl) { rlo[r] = value; rhi[r] = value; }
+              push[r] = 1ull << bl; /* a scalar shift */
+              val[r] |= push[r];
+            }
+            lo0[r] = rlo[r]; hi0[r] = rhi[r];
+          }
+          int rounds = 0, revisions = 0;
+          const int fail_var = C.fixpoint(rlo, rhi, pushed, push, dl, dh, val, rounds, revisions);
+          if (rounds != 0) __builtin_amdgcn_s_setprio(0);
+          acc_revs += revisions;
+          int open_vars = 0;
+#pragma unroll
+          for (int r = 0; r < R; r++) {
+            open_vars += __popcll(__ballot(rlo[r] != rhi[r]));
+            acc_props += (rlo[r] - lo0[r]) + (hi0[r] - rhi[r]);
+          }
+          if (fail_var >= 0) {
+            acc_cuts++;
+          } else if (open_vars > 0) {
+            const size_t orow = (region + (size_t)fill) * n;
+#pragma unroll
+            for (int r = 0; r < R; r++)
+              if (live[r]) stage[orow + lane + r * CS_WAVE] = cs_interval(rlo[r] + b0[r], rhi[r] + b0[r]);
+            fill++;
+          } else {
+            acc_sol++;
+            if (store_open) {
+              unsigned long long s0 = 0ull;
+              if (lane == 0) s0 = atomicAdd(io.stored, 1ull);
+              const long long slot0 = (long long)(((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(s0 >> 32)) << 32) |
+                                                  (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)s0));
+              if (slot0 < io.max_solutions) {
+#pragma unroll
+                for (int r = 0; r < R; r++)
+                  if (live[r]) io.solutions[(size_t)slot0 * n + lane + r * CS_WAVE] = rlo[r] + b0[r];
+              }
+              if (slot0 + 1 >= io.max_solutions) store_open = 0;
+            }
+          }
+        }
+      }
+    }
+    p_cur = p_next;
+  }
+  const int props = cs_wave_sum(acc_props);
+  if (lane == 0) {
+    io.fill[wave_global] = (unsigned)fill;
+    unsigned long long *st = io.wstat + (size_t)wave_global * CS_STEP_STATS;
+    st[0] = (unsigned long long)acc_nodes;
+    st[1] = (unsigned long long)acc_cuts;
+    st[2] = (unsigned long long)props;
+    st[3] = (unsigned long long)acc_revs;
+    st[4] = (unsigned long long)acc_sol;
+    st[5] = (unsigned long long)acc_parents;
+  }
+#undef CS_STEP_DRAW
+}
+
 /* Appends the waves' regions to the pool (after the parents nobody drew) and adds the waves' counters up.
  * Workgroup w: rows before region w's = sum of fill[0 .. w), then a flat copy of its fill[w] * n elements.
  * out[0] = parents consumed, out[1] = survivors, out[2 ..] = nodes, cuts, props, revisions, solutions, out[7] = rows in
@@ -468,7 +695,8 @@ __global__ __launch_bounds__(256) void cs_collect(const unsigned *__restrict__ f
                                                   const unsigned long long *__restrict__ stored) {
   __shared__ unsigned long long s_red[256];
   const int w = blockIdx.x, t = threadIdx.x;
-  const unsigned long long drawn = (unsigned long long)*ticket * (unsigned long long)chunk;
+  /* chunk == 0: the launch drew every parent (cs_step_shave, sized for the worst case) */
+  const unsigned long long drawn = chunk == 0 ? (unsigned long long)parents : (unsigned long long)*ticket * (unsigned long long)chunk;
   const long long consumed = drawn < (unsigned long long)parents ? (long long)drawn : (long long)parents;
   unsigned long long before = 0ull;
   for (int i = t; i < w; i += 256) before += fill[i];

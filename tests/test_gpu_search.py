@@ -103,7 +103,7 @@ def test_schedule_16_incumbents_are_feasible_schedules():
     assert more["best"] <= st["best"]
 
 
-@pytest.mark.parametrize("which", ["queens7", "offsets6x5", "offsets5x9"])
+@pytest.mark.parametrize("which", ["queens7", "offsets6x5", "offsets5x9", "offsets40x8", "offsets64x8", "sudoku9", "sudoku16"])
 def test_search_counters_match_oracle_tree_on_all(which):
     """For ALL the set of explored nodes does not depend on the walking order as long as the
     branching variable of a state is a function of the state: compare CALLS/CUTS/solutions with a
@@ -111,8 +111,12 @@ def test_search_counters_match_oracle_tree_on_all(which):
     that a parent's own forbidden set rules out without launching them; the walk propagates every one)."""
     from csolve_amd import problems
     from oracle.cs_oracle import Model as OModel, Oracle
+    # the last four take cs_step_shave (one wave per parent: 40 and 64 variables in one register per lane, 81 in two,
+    # 256 in four); the first three cs_step_packed
     text = {"queens7": lambda: problems.queens(7, "ALL"), "offsets6x5": lambda: problems.offsets(6, 5, 2, "ALL"),
-            "offsets5x9": lambda: problems.offsets(5, 9, 4, "ALL")}[which]()
+            "offsets5x9": lambda: problems.offsets(5, 9, 4, "ALL"), "offsets40x8": lambda: problems.offsets(40, 8, 1, "ALL"),
+            "offsets64x8": lambda: problems.offsets(64, 8, 1, "ALL"), "sudoku9": lambda: problems.sudoku(3, 0.35, 1, "ALL"),
+            "sudoku16": lambda: problems.sudoku(4, 0.6, 3, "ALL")}[which]()
     model, s, st = _solve(text)
     om = OModel.parse(text)
     om.set_domains(model.domains())
@@ -135,6 +139,28 @@ def test_search_counters_match_oracle_tree_on_all(which):
             else:
                 stack.append(out)
     assert (st["nodes"], st["cuts"], st["solutions"]) == (calls, cuts, sols)
+
+
+@pytest.mark.parametrize("which", ["queens11", "offsets40x8", "sudoku9", "sudoku9_30"])
+def test_fused_levels_walk_the_tree_of_the_separate_kernels(which, monkeypatch):
+    """ALL through the level kernels of cs_step.hip.h (one launch per frontier) and, with CSGPU_SEARCH_FUSED=0, through
+    branch / emit / fixpoint / classify / scatter: the same nodes, cuts, solutions and propagations; stored solutions
+    satisfy the root"""
+    from csolve_amd import problems
+    text = {"queens11": lambda: problems.queens(11, "ALL"), "offsets40x8": lambda: problems.offsets(40, 8, 1, "ALL"),
+            "sudoku9": lambda: problems.sudoku(3, 0.35, 1, "ALL"), "sudoku9_30": lambda: problems.sudoku(3, 0.30, 3, "ALL")}[which]()
+    runs = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("CSGPU_SEARCH_FUSED", fused)
+        model, s, st = _solve(text)
+        assert st["done"] == 1 and st["pool"] == 0
+        runs.append({k: st[k] for k in ("nodes", "cuts", "solutions", "props")})
+        rows = s.solutions(32)
+        assert len(rows) == min(32, st["solutions"])
+        for row in rows:
+            truth = model.eval_root(torch.from_numpy(np.stack([row, row], 1)[None].astype(np.int32)).cuda())
+            assert int(truth[0]) == 1
+    assert runs[0] == runs[1], runs
 
 
 def test_take_and_put_move_subtrees_between_engines():

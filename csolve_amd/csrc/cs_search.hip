@@ -502,7 +502,8 @@ __global__ __launch_bounds__(SB) void cs_classify_count(const csgpu_result *__re
   int status = -2, props = 0, revs = 0;
   if (i < children) {
     status = res[i].status;
-    props = res[i].props;
+    props = status >= 0 ? res[i].props : 0; /* propagations of consistent children only: on a != network those are the
+                                             * reference's PROPS; an inconsistent child's count depends on the revision order */
     revs = res[i].revisions;
   }
   int ps = status > 0, pk = status == 0, pc = status == -1, pp = props, pr = revs;
@@ -571,7 +572,7 @@ __global__ __launch_bounds__(1024) void cs_classify_small(const csgpu_result *__
       if (i < children) {
         const csgpu_result r = res[i];
         status[q] = r.status;
-        props += r.props;
+        props += r.status >= 0 ? r.props : 0;
         revs += r.revisions;
         cuts += r.status == -1;
       }

@@ -356,7 +356,9 @@ __global__ __launch_bounds__(1024, 8) void cs_step_packed(int n, const unsigned 
     const u64 openm = cs_segments_any<G>(__ballot(live && rl != rh)) & validm;
     const u64 survm = openm & ~failedm, complm = validm & ~failedm & ~openm;
     acc_fail += __popcll(failedm) >> LOG_S;
-    acc_props += valid ? (rl - rl0) + (rh0 - rh) : 0;
+    /* propagations of consistent children only: there the count is the reference's PROPS (every bound move is one
+     * narrowing whatever the order); what an inconsistent child did before it failed depends on the revision order */
+    acc_props += __builtin_amdgcn_inverse_ballot_w64(validm & ~failedm) ? (rl - rl0) + (rh0 - rh) : 0;
     acc_revs += __builtin_amdgcn_inverse_ballot_w64(pushedm) ? deg : 0;
     if (survm != 0ull) {
       const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(survm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)survm, 0u)) >> LOG_S;
@@ -639,7 +641,7 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_step_shave(int n, c
 #pragma unroll
           for (int r = 0; r < R; r++) {
             open_vars += __popcll(__ballot(rlo[r] != rhi[r]));
-            acc_props += (rlo[r] - lo0[r]) + (hi0[r] - rhi[r]);
+            if (fail_var < 0) acc_props += (rlo[r] - lo0[r]) + (hi0[r] - rhi[r]); /* consistent children only: the reference's PROPS */
           }
           if (fail_var >= 0) {
             acc_cuts++;

@@ -122,7 +122,7 @@ def test_search_counters_match_oracle_tree_on_all(which):
     om.set_domains(model.domains())
     om.index()
     orc = Oracle(om)
-    calls = cuts = sols = 0
+    calls = cuts = sols = props = 0
     stack = [model.domains()]
     while stack:
         state = stack.pop()
@@ -134,11 +134,15 @@ def test_search_counters_match_oracle_tree_on_all(which):
             status, out = orc.instance(state, v, val, val)
             if status < 0:
                 cuts += 1
-            elif (out[:, 0] == out[:, 1]).all():
+                continue
+            props += status
+            if (out[:, 0] == out[:, 1]).all():
                 sols += 1
             else:
                 stack.append(out)
     assert (st["nodes"], st["cuts"], st["solutions"]) == (calls, cuts, sols)
+    # the engine's propagations are those of the consistent children: on a != network the reference's PROPS
+    assert st["props"] == props
 
 
 @pytest.mark.parametrize("which", ["queens11", "offsets40x8", "sudoku9", "sudoku9_30"])

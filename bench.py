@@ -114,8 +114,11 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 def measured_traffic(kernel_name, workload_key, instances):
     """HBM bytes per launch from the committed PMC profile of this very kernel and workload
     (profiles/*_pmc_*.json, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in their own passes, FETCH_SIZE
-    doubled as MI355X_MICROARCH.md prescribes for gfx950), or None when there is no such profile.
-    workload_key: "queens-64", "sudoku-25x25", ... (the first words of the profile's "workload")."""
+    doubled as MI355X_MICROARCH.md prescribes for gfx950), or (None, None) when there is no such profile.
+    workload_key: "queens-64", "sudoku-25x25", ... (the first words of the profile's "workload").
+    -> (bytes, source): the figure is NOT measured in this run (counters need the profiler's own passes); `source` names
+    the profile file it was taken from, the commit that profile was made at and the command, so that a reader can tell
+    a stale profile from a current one."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_*.json")), reverse=True):
         try:
@@ -124,8 +127,10 @@ def measured_traffic(kernel_name, workload_key, instances):
             continue
         if kernel_name in rec.get("kernel", "") and rec.get("workload", "").startswith(workload_key + " ") and \
                 f"{instances} instances" in rec.get("workload", "") and "hbm_traffic_bytes_per_launch" in rec:
-            return rec["hbm_traffic_bytes_per_launch"]
-    return None
+            return rec["hbm_traffic_bytes_per_launch"], {
+                "measured_in_this_run": False, "profile": os.path.relpath(path, ROOT), "profile_commit": rec.get("commit"),
+                "profile_command": rec.get("command"), "workload": rec.get("workload")}
+    return None, None
 
 
 def make_instances(model, count, seed, walks=8192, with_sets=False, restore_kernel=0):
@@ -450,7 +455,9 @@ def search_record(args, rank, world, dist):
     q = args.search_queens
     rec(f"queens{q}_all", problems.queens(q, "ALL"), steps=args.search_steps, warmup=1)
     out[f"queens{q}_all"]["workload"] = f"queens-{q} ALL, the whole tree, sharded GPU-per-subtree (BASELINE configs[3] shape); strong scaling"
-    rec("queens128_all", problems.queens(128, "ALL"), steps=1, warmup=0, time_limit=args.search_time_limit)
+    # (a pool of 2^25 rows, 32 GB of interval rows: with the default 2^22 the frontiers stay small -- the pool bounds how
+    # many parents a depth-first walk in batches may take -- and the same run explores 1.0e9 instead of 1.7e9 nodes/s)
+    rec("queens128_all", problems.queens(128, "ALL"), steps=1, warmup=0, time_limit=args.search_time_limit, pool=1 << 25)
     out["queens128_all"]["workload"] = (f"queens-128 ALL stopped after {args.search_time_limit} s on every rank (the reference's -t): "
                                         f"nodes explored per second by the whole job")
     sched = args.search_record_schedule
@@ -472,7 +479,9 @@ def main():
                     "general kernel) instead of queens (BASELINE configs[4] shape)")
     ap.add_argument("--sudoku", type=int, default=0, help="box size N of an N^2 x N^2 sudoku-shaped != network instead of "
                     "queens (5 = BASELINE configs[2], 25x25)")
-    ap.add_argument("--instances", type=int, default=1 << 18, help="node instances per GPU")
+    ap.add_argument("--instances", type=int, default=1 << 20, help="node instances per GPU (2^20 queens-64 instances are 1.1 GB per "
+                    "launch: four times the 256 MB Infinity Cache, so a repeated launch cannot be served from it; a launch "
+                    "of 2^18 takes 66 us instead of the 57 us a quarter of the large one takes: ramp and tail of a launch)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch the timed steps one by one instead of as one hipGraph")
@@ -551,8 +560,8 @@ def main():
     problem_name = f"queens-{n_q} "
     workload_key = f"queens-{n_q}"
     if args.sudoku:
-        text = problems.sudoku(args.sudoku, 0.3, 1)
-        problem_name = f"sudoku-{args.sudoku ** 2}x{args.sudoku ** 2} (30 % givens) "
+        text = problems.sudoku(args.sudoku, 0.4, 1)
+        problem_name = f"sudoku-{args.sudoku ** 2}x{args.sudoku ** 2} (40 % givens, SURVEY 8d(3)) "
         workload_key = f"sudoku-{args.sudoku ** 2}x{args.sudoku ** 2}"
     if args.schedule:
         text = problems.schedule(args.schedule, 1)
@@ -716,7 +725,7 @@ def run_propagation_legs(args, text, instances, seed, dist=None, headline_only=F
     full_lanes = n in (64, 128, 256)
     leg("state_only", "csgpu_propagate_batch (interval states in, interval states out)", k1,
         lambda: model.propagate(states_in, nodes, so1, r1), so1, r1, 8 * n,
-        stores_all=(k1 == "cs_propagate_ne_shave" and full_lanes), sets_precomputed=False)
+        stores_all=False, sets_precomputed=False)
     headline = "state_only"
     if want_sets and not headline_only:
         so2 = torch.empty((B, n, 2), dtype=torch.int32, device="cuda")
@@ -745,22 +754,29 @@ def run_propagation_legs(args, text, instances, seed, dist=None, headline_only=F
 
 
 def roofline_record(leg, workload_key, B):
-    """HBM roofline of one leg.  `achieved` / `frac` are on the NECESSARY bytes of a node instance -- the state in
-    and out (`struct val_t` per variable: 16 n) plus the 16-byte node record and the 16-byte result --
-    whatever the layout of the leg moves on top of that is reported as layout_*."""
+    """HBM roofline of one leg.  `achieved` / `frac` are on the bytes a node instance NEEDS: the parent state in
+    (`struct val_t` per variable: 8 n), the 16-byte node record, the 16-byte result, and the state out (8 n) for the
+    CONSISTENT nodes only -- an inconsistent node has no fixpoint to store.  SURVEY 8d's per-node figure (16 n + 32 for
+    every node) is kept as `survey_8d_*`; what the layout of the leg moves on top (forbidden sets) as layout_*."""
     n = leg["n"]
-    necessary = (16 * n + 32) * B
-    t = leg["kernel_ms"] * 1e-3
     res_h = leg["results"]
+    consistent = int((res_h[:, 0] >= 0).sum())
+    needed = (8 * n + 32) * B + 8 * n * consistent
+    survey_node_bytes = (16 * n + 32) * B
+    t = leg["kernel_ms"] * 1e-3
     survey_bytes = 32 * int(res_h[:, 2].sum()) + 8 * int(res_h[:, 1].sum()) + 16 * n * B
-    traffic = measured_traffic(leg["kernel"], workload_key, B)
-    return {"bound": "hbm", "achieved": necessary / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": necessary / t / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+    traffic, source = measured_traffic(leg["kernel"], workload_key, B)
+    return {"bound": "hbm", "achieved": needed / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": needed / t / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": source,
             "kernel": leg["kernel"], "kernel_ms": leg["kernel_ms"], "launch": leg["launch"],
-            "algorithmic_bytes_per_launch": necessary, "bytes_per_node_instance": 16 * n + 32,
+            "algorithmic_bytes_per_launch": needed, "consistent_nodes": consistent,
+            "bytes_counted": "8 n + 32 per node instance (state in, record, result) + 8 n per CONSISTENT node (state out)",
+            "bytes_per_node_instance": 16 * n + 32,
+            "survey_8d_node_bytes_per_launch": survey_node_bytes,
+            "survey_8d_node_frac": survey_node_bytes / t / 1e9 / HBM_PEAK_GBS,
             "layout_bytes_per_launch": leg["layout_bytes"], "layout_gbps": leg["layout_bytes"] / t / 1e9,
             "layout_frac": leg["layout_bytes"] / t / 1e9 / HBM_PEAK_GBS,
-            "traffic_over_necessary": None if traffic is None else traffic / necessary,
+            "traffic_over_necessary": None if traffic is None else traffic / needed,
             "output_rows_stored": leg["stored_rows"],
             "survey_8d_formula_gbps": survey_bytes / t / 1e9}
 
@@ -771,7 +787,7 @@ def leg_summary(leg):
     return {"entry": leg["entry"], "kernel": leg["kernel"], "kernel_ms": leg["kernel_ms"], "nodes_per_s": B / t,
             "propagations_per_s": int(leg["results"][ok, 1].sum()) / t,
             "forbidden_sets_precomputed": leg["sets_precomputed"],
-            "frac_of_hbm_peak_on_necessary_bytes": (16 * n + 32) * B / t / 1e9 / HBM_PEAK_GBS,
+            "frac_of_hbm_peak_on_necessary_bytes": ((8 * n + 32) * B + 8 * n * int(ok.sum())) / t / 1e9 / HBM_PEAK_GBS,
             "frac_of_hbm_peak_on_layout_bytes": leg["layout_bytes"] / t / 1e9 / HBM_PEAK_GBS,
             "layout_bytes_per_node": leg["layout_bytes"] / B}
 
@@ -818,19 +834,19 @@ def end_to_end_record():
 
 
 def queens128_record(args):
-    """The north-star instance next to the headline: queens-128, 2^17 seeded node instances, state-only entry,
-    every instance re-checked against the compiled reference (one pass, about 3 s of one host core)."""
+    """The north-star instance next to the headline: queens-128, 2^19 seeded node instances (1.1 GB per launch), state-only
+    entry, a sample of the instances re-checked against the compiled reference (about 6 s of one host core)."""
     import copy
     a = copy.copy(args)
     a.queens, a.sudoku, a.schedule, a.layout = 128, 0, 0, "intervals"
     a.cpu_seconds = min(args.cpu_seconds, 6.0)
     text = problems.queens(128)
-    legs = run_propagation_legs(a, text, 1 << 17, seed=777, headline_only=True, steps=min(args.steps, 50))
+    legs = run_propagation_legs(a, text, 1 << 19, seed=777, headline_only=True, steps=min(args.steps, 50))
     leg = legs["legs"]["state_only"]
     rec = roofline_record(leg, "queens-128", legs["B"])
     ok = leg["results"][:, 0] >= 0
     t = leg["kernel_ms"] * 1e-3
-    out = {"workload": "queens-128 propagation-only fixpoint, 131072 seeded random-walk node instances resident in HBM",
+    out = {"workload": "queens-128 propagation-only fixpoint, 524288 seeded random-walk node instances resident in HBM",
            "entry": leg["entry"], "forbidden_sets_precomputed": False, "steps": leg["steps"],
            "nodes_per_s": legs["B"] / t, "value": int(leg["results"][ok, 1].sum()) / t, "unit": "propagations/s",
            "roofline": rec}
@@ -846,13 +862,13 @@ def sudoku25_record(args):
     a = copy.copy(args)
     a.queens, a.sudoku, a.schedule, a.layout = 64, 5, 0, "intervals"
     a.cpu_seconds = min(args.cpu_seconds, 4.0)
-    text = problems.sudoku(5, 0.3, 1)
+    text = problems.sudoku(5, 0.4, 1)  # 40 % of a seeded valid grid revealed
     legs = run_propagation_legs(a, text, 1 << 18, seed=555, headline_only=True, steps=min(args.steps, 30))
     leg = legs["legs"]["state_only"]
     rec = roofline_record(leg, "sudoku-25x25", legs["B"])
     ok = leg["results"][:, 0] >= 0
     t = leg["kernel_ms"] * 1e-3
-    out = {"workload": "sudoku-25x25 (30 % givens) propagation-only fixpoint, 262144 seeded random-walk node instances resident in HBM",
+    out = {"workload": "sudoku-25x25 (40 % givens) propagation-only fixpoint, 262144 seeded random-walk node instances resident in HBM",
            "entry": leg["entry"], "forbidden_sets_precomputed": False, "steps": leg["steps"],
            "nodes_per_s": legs["B"] / t, "value": int(leg["results"][ok, 1].sum()) / t, "unit": "propagations/s",
            "roofline": rec}

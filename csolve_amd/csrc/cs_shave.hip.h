@@ -523,10 +523,16 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_shave(
       }
       const int props = cs_wave_sum(shaved);
       const size_t orow = (size_t)(unsigned)(base + j) * (unsigned)n;
-      if (FULL) {
+#ifndef CS_SHAVE_STORE_FAILED
+/* 1: with FULL an inconsistent node stores its meaningless row too (no branch around the store: round 2's form).  0: it
+ * stores nothing -- 12 % of the bench's queens-64 nodes are inconsistent, their rows were 6 % of the launch's traffic:
+ * queens-64 66.7 -> 65.1 us per 2^18 nodes, queens-128 60.4 -> 58.8 us (same box, tools/ab_bench.sh) */
+#define CS_SHAVE_STORE_FAILED 0
+#endif
+      if (FULL && (CS_SHAVE_STORE_FAILED || !failed)) {
 #pragma unroll
         for (int r = 0; r < R; r++) states_out[orow + lane + r * CS_WAVE] = cs_interval(rlo[r] + b0[r], rhi[r] + b0[r]);
-      } else if (!failed) {
+      } else if (!FULL && !failed) {
 #pragma unroll
         for (int r = 0; r < R; r++)
           if (live[r]) states_out[orow + lane + r * CS_WAVE] = cs_interval(rlo[r] + b0[r], rhi[r] + b0[r]);

@@ -3,6 +3,7 @@
  * next to this one, every interval computation happens in the kernels of
  * cs_kernels.hip.h.  Nothing here evaluates or narrows a domain on the CPU. */
 #include <hip/hip_runtime.h>
+#include <chrono>
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -92,6 +93,15 @@ struct csgpu_model {
   cs_val *d_one_in, *d_one_out;  /* device views of the four parts */
   cs_node_in *d_one_node;
   cs_node_out *d_one_res;
+  /* the resident single-node server (cs_shave_server): its mailbox in coherent host memory, its stream, the last
+   * request number; srv_off: not used for this model (it does not qualify, or CSGPU_SERVER=0) */
+  unsigned char *h_box;   /* [cs_mailbox_head | state_in | state_out | trace] */
+  size_t box_state_off, box_out_off, box_trace_off;
+  hipStream_t srv_stream;
+  unsigned srv_seq;
+  int srv_off, srv_launched;
+  double srv_seconds[4]; /* host copy in, ring + wait, copy out, (re)starts -- csgpu_debug_one_timing */
+  uint64_t srv_calls, srv_starts;
   /* staging of csgpu_propagate_values (mapped pinned memory, grown on demand) */
   unsigned char *h_values, *d_values;
   size_t values_cap;
@@ -209,7 +219,15 @@ extern "C" int csgpu_model_from_host(cs_model *host, int lists_final, int domain
 
 extern "C" cs_model *csgpu_model_host(csgpu_model *m) { return m ? m->host : NULL; }
 
+static void server_stop(csgpu_model *m);
+
 static void free_device(csgpu_model *m) {
+  server_stop(m); /* before anything is freed: the resident wave reads the tables */
+  if (m->h_box != NULL) (void)hipHostFree(m->h_box);
+  m->h_box = NULL;
+  if (m->srv_stream != NULL) (void)hipStreamDestroy(m->srv_stream);
+  m->srv_stream = NULL;
+  m->srv_off = 0;
   (void)hipFree(m->d_adj_off); (void)hipFree(m->d_adj); (void)hipFree(m->d_clause);
   (void)hipFree(m->d_tree_off); (void)hipFree(m->d_tnode); (void)hipFree(m->d_tkid); (void)hipFree(m->d_tree_want);
   (void)hipFree(m->d_lit);
@@ -378,6 +396,7 @@ extern "C" int csgpu_model_root_propagate_limit(csgpu_model *m, int64_t limit, i
   int rc = upload_image(g, &own, &tab);
   cs_val *d_in = NULL, *d_out = NULL;
   cs_node_out *d_res = NULL;
+  int *d_conv = NULL, conv = 1;
   cs_node_out res;
   const size_t nbytes = (size_t)(h->n_vars ? h->n_vars : 1) * sizeof(cs_val);
   const size_t lds = (size_t)h->n_vars * sizeof(cs_val) + 4 * sizeof(unsigned);
@@ -385,24 +404,37 @@ extern "C" int csgpu_model_root_propagate_limit(csgpu_model *m, int64_t limit, i
   if (rc == CSGPU_OK) rc = lds_limit(lds, (const void *)cs_propagate_sweeps);
   if (rc == CSGPU_OK) {
     if ((e = hipMalloc((void **)&d_in, nbytes)) != hipSuccess || (e = hipMalloc((void **)&d_out, nbytes)) != hipSuccess ||
-        (e = hipMalloc((void **)&d_res, sizeof res)) != hipSuccess ||
+        (e = hipMalloc((void **)&d_res, sizeof res)) != hipSuccess || (e = hipMalloc((void **)&d_conv, sizeof(int))) != hipSuccess ||
         (e = hipMemcpy(d_in, h->dom, (size_t)h->n_vars * sizeof(cs_val), hipMemcpyHostToDevice)) != hipSuccess)
       rc = set_err(CSGPU_E_HIP, "root propagate setup: %s", hipGetErrorString(e));
   }
   if (rc == CSGPU_OK) {
     /* propagate(root, limit) stops after limit + 1 sweeps (propagate.c:479-483) */
     const int max_rounds = limit < 0 || limit >= 0x7ffffffe ? 0x7fffffff : (int)limit + 1;
-    hipLaunchKernelGGL(cs_propagate_sweeps, dim3(1), dim3(CS_BLOCK), lds, 0, tab, d_in, d_out, d_res, max_rounds);
+    /* All clauses of a round in parallel first: a round never narrows more than a sweep of the reference, so a
+     * fixpoint (or an inconsistency) reached within the limit is the reference's.  Only when the limit cuts the
+     * iteration short do the states depend on the order: then the same number of sweeps is run again from the
+     * start in the reference's own order, one clause after the other (propagate.c:379-392, 474-485). */
+    hipLaunchKernelGGL(cs_propagate_sweeps, dim3(1), dim3(CS_BLOCK), lds, 0, tab, d_in, d_out, d_res, max_rounds, 0, d_conv);
     if ((e = hipGetLastError()) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess ||
         (e = hipMemcpy(&res, d_res, sizeof res, hipMemcpyDeviceToHost)) != hipSuccess ||
-        (e = hipMemcpy(h->dom, d_out, (size_t)h->n_vars * sizeof(cs_val), hipMemcpyDeviceToHost)) != hipSuccess)
+        (e = hipMemcpy(&conv, d_conv, sizeof conv, hipMemcpyDeviceToHost)) != hipSuccess)
       rc = set_err(CSGPU_E_HIP, "root propagate: %s", hipGetErrorString(e));
+    if (rc == CSGPU_OK && res.status >= 0 && !conv) {
+      hipLaunchKernelGGL(cs_propagate_sweeps, dim3(1), dim3(CS_BLOCK), lds, 0, tab, d_in, d_out, d_res, max_rounds, 1, d_conv);
+      if ((e = hipGetLastError()) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess ||
+          (e = hipMemcpy(&res, d_res, sizeof res, hipMemcpyDeviceToHost)) != hipSuccess)
+        rc = set_err(CSGPU_E_HIP, "root propagate (sequential sweeps): %s", hipGetErrorString(e));
+    }
+    if (rc == CSGPU_OK && (e = hipMemcpy(h->dom, d_out, (size_t)h->n_vars * sizeof(cs_val), hipMemcpyDeviceToHost)) != hipSuccess)
+      rc = set_err(CSGPU_E_HIP, "root propagate: %s", hipGetErrorString(e));
+    if (rc != CSGPU_OK) { /* reported below */ }
     else {
       *status = res.status < 0 ? -1 : res.props;
       if (rounds != NULL) *rounds = res.rounds;
     }
   }
-  (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_res);
+  (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_res); (void)hipFree(d_conv);
   free_tables(&own);
   cs_dev_image_free(g);
   return rc;
@@ -1687,6 +1719,164 @@ extern "C" int csgpu_propagate_one_traced(const csgpu_model *cm, const csgpu_val
 }
 
 /* One node of a pure != network with its trail as causes: kernel 7's tracing variant, one wave. */
+/* ---- the resident single-node server (cs_shave.hip.h) ---- */
+static const void *shave_server_kernel(int width, int n_vars, int slots) {
+  const int chunks = (n_vars + CS_WAVE - 1) / CS_WAVE;
+  const int r = chunks <= 1 ? 1 : (chunks <= 2 ? 2 : 4);
+  const int sl = slots == 1 ? 1 : (slots == 3 ? 3 : 0);
+#define CS_PICK_S(E, RR)                                                                           \
+  switch (sl) {                                                                                    \
+  case 1: return (const void *)cs_shave_server<E, RR, 1>;                                           \
+  case 3: return (const void *)cs_shave_server<E, RR, 3>;                                           \
+  default: return (const void *)cs_shave_server<E, RR, 0>;                                          \
+  }
+#define CS_PICK(E)                                                                                 \
+  switch (r) {                                                                                     \
+  case 1: CS_PICK_S(E, 1)                                                                          \
+  case 2: CS_PICK_S(E, 2)                                                                          \
+  default: CS_PICK_S(E, 4)                                                                         \
+  }
+  if (width == 1) { CS_PICK(unsigned char) }
+  CS_PICK(unsigned short)
+#undef CS_PICK
+#undef CS_PICK_S
+}
+
+static double srv_now(void) {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+static cs_mailbox_head *srv_box(const csgpu_model *m) { return (cs_mailbox_head *)m->h_box; }
+
+/* does this model use the server?  (kernel 7's models whose table leaves room for the trail in LDS) */
+static int server_usable(csgpu_model *m) {
+  if (m->srv_off) return 0;
+  if (m->h_box != NULL) return 1;
+  const char *e = getenv("CSGPU_SERVER");
+  const size_t lds = ((m->dense_bytes + 15) & ~(size_t)15) + CS_SHAVE_TRACE_LDS * 16;
+  if ((e != NULL && e[0] == '0') || !m->dense_waves || lds > 160u * 1024u) { m->srv_off = 1; return 0; }
+  const size_t nbytes = ((size_t)m->host->n_vars * sizeof(cs_val) + 63) & ~(size_t)63;
+  m->box_state_off = (sizeof(cs_mailbox_head) + 63) & ~(size_t)63;
+  m->box_out_off = m->box_state_off + nbytes;
+  m->box_trace_off = m->box_out_off + nbytes;
+  const size_t total = m->box_trace_off + (size_t)CS_SHAVE_TRACE_LDS * 16;
+  if (hipHostMalloc((void **)&m->h_box, total, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+      hipStreamCreateWithFlags(&m->srv_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipFuncSetAttribute(shave_server_kernel(m->img->dense_width, m->host->n_vars, m->img->dense_slots),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    (void)hipGetLastError();
+    if (m->h_box != NULL) (void)hipHostFree(m->h_box);
+    m->h_box = NULL;
+    m->srv_off = 1;
+    return 0;
+  }
+  memset(m->h_box, 0, total);
+  m->srv_seq = 0;
+  return 1;
+}
+
+/* start a resident wave (none is alive) and wait until it says so */
+static int server_start(csgpu_model *m) {
+  cs_mailbox_head *box = srv_box(m);
+  if (m->srv_launched) HIP_TRY(hipStreamSynchronize(m->srv_stream)); /* the previous one has left (alive == 0): reap it */
+  void *dev = NULL;
+  HIP_TRY(hipHostGetDevicePointer(&dev, m->h_box, 0));
+  cs_mailbox_head *d_box = (cs_mailbox_head *)dev;
+  unsigned long long *d_in = (unsigned long long *)((unsigned char *)dev + m->box_state_off);
+  unsigned long long *d_out = (unsigned long long *)((unsigned char *)dev + m->box_out_off);
+  int4 *d_trace = (int4 *)((unsigned char *)dev + m->box_trace_off);
+  int n = m->host->n_vars, slots = m->img->dense_slots, dmin_d = m->img->dense_dmin;
+  const void *tab_d = m->d_dense_tab;
+  const int *root_lo_d = m->d_root_lo, *sym_off = m->d_sym_off;
+  unsigned cap = CS_SHAVE_TRACE_LDS;
+  unsigned long long idle = 200000ull; /* 2 ms of the 100 MHz clock: a search calls every few microseconds */
+  { const char *e = getenv("CSGPU_SERVER_IDLE_US"); if (e != NULL && atoll(e) > 0) idle = (unsigned long long)atoll(e) * 100ull; }
+  void *args[] = { &n, &tab_d, &slots, &dmin_d, &root_lo_d, &sym_off, &d_box, &d_in, &d_out, &d_trace, &cap, &idle };
+  const size_t lds = ((m->dense_bytes + 15) & ~(size_t)15) + CS_SHAVE_TRACE_LDS * 16;
+  HIP_TRY(hipLaunchKernel(shave_server_kernel(m->img->dense_width, n, slots), dim3(1), dim3((unsigned)(m->dense_waves * CS_WAVE)),
+                          args, lds, m->srv_stream));
+  m->srv_launched = 1;
+  m->srv_starts++;
+  const double t0 = srv_now();
+  while (__atomic_load_n(&box->alive, __ATOMIC_ACQUIRE) == 0u) {
+    /* a wave that has already served the pending request and left again also counts */
+    if (__atomic_load_n(&box->ack_seq, __ATOMIC_ACQUIRE) == m->srv_seq && hipStreamQuery(m->srv_stream) == hipSuccess) break;
+    if (srv_now() - t0 > 10.0) return set_err(CSGPU_E_HIP, "the single-node server did not start");
+  }
+  return CSGPU_OK;
+}
+
+static void server_stop(csgpu_model *m) {
+  if (m->h_box == NULL || !m->srv_launched) return;
+  cs_mailbox_head *box = srv_box(m);
+  __atomic_store_n(&box->stop, 1u, __ATOMIC_RELEASE);
+  (void)hipStreamSynchronize(m->srv_stream);
+  __atomic_store_n(&box->stop, 0u, __ATOMIC_RELEASE);
+  m->srv_launched = 0;
+}
+
+/* one node through the mailbox; trace == NULL: no trail wanted */
+static int server_call(csgpu_model *m, const csgpu_val *state, csgpu_node node, csgpu_val *state_out, csgpu_result *result,
+                       int32_t *trace, int32_t cap, int32_t *count) {
+  cs_mailbox_head *box = srv_box(m);
+  const size_t nbytes = (size_t)m->host->n_vars * sizeof(cs_val);
+  const double t0 = srv_now();
+  memcpy(m->h_box + m->box_state_off, state, nbytes);
+  box->node.var = node.var; box->node.lo = node.lo; box->node.hi = node.hi; box->node.parent = 0;
+  box->want_trace = trace != NULL ? 1u : 0u;
+  const unsigned seq = ++m->srv_seq;
+  const double t1 = srv_now();
+  __atomic_store_n(&box->req_seq, seq, __ATOMIC_RELEASE);
+  double t_start = 0.0;
+  if (__atomic_load_n(&box->alive, __ATOMIC_ACQUIRE) == 0u) {
+    const double ts = srv_now();
+    const int rc = server_start(m);
+    if (rc != CSGPU_OK) return rc;
+    t_start = srv_now() - ts;
+  }
+  unsigned spins = 0;
+  while (__atomic_load_n(&box->ack_seq, __ATOMIC_ACQUIRE) != seq) {
+    if ((++spins & 0xfffu) == 0u) {
+      /* the wave may have left (idle for too long) just before the request arrived: start another, which finds it */
+      if (__atomic_load_n(&box->alive, __ATOMIC_ACQUIRE) == 0u && __atomic_load_n(&box->ack_seq, __ATOMIC_ACQUIRE) != seq) {
+        const double ts = srv_now();
+        const int rc = server_start(m);
+        if (rc != CSGPU_OK) return rc;
+        t_start += srv_now() - ts;
+      }
+      if (srv_now() - t1 > 30.0) return set_err(CSGPU_E_HIP, "the single-node server does not answer");
+    }
+  }
+  const double t2 = srv_now();
+  result->status = box->result.status; result->props = box->result.props;
+  result->revisions = box->result.revisions; result->rounds = box->result.rounds;
+  if (result->status >= 0) memcpy(state_out, m->h_box + m->box_out_off, nbytes);
+  if (trace != NULL) {
+    const unsigned made = box->trace_n;
+    *count = (int32_t)made;
+    unsigned kept = made < CS_SHAVE_TRACE_LDS ? made : CS_SHAVE_TRACE_LDS;
+    if (kept > (unsigned)cap) kept = (unsigned)cap;
+    memcpy(trace, m->h_box + m->box_trace_off, (size_t)kept * 16);
+  }
+  const double t3 = srv_now();
+  m->srv_seconds[0] += t1 - t0;
+  m->srv_seconds[1] += t2 - t1 - t_start;
+  m->srv_seconds[2] += t3 - t2;
+  m->srv_seconds[3] += t_start;
+  m->srv_calls++;
+  return CSGPU_OK;
+}
+
+/* where the time of the single-node calls went: seconds[0..3] = host copy in, ring + wait, copy out, server (re)starts;
+ * calls, starts.  For the launch path (CSGPU_SERVER=0): copy in, launch submit, wait, copy out (starts = 0). */
+extern "C" int csgpu_debug_one_timing(const csgpu_model *m, double *seconds, uint64_t *calls, uint64_t *starts) {
+  if (m == NULL || seconds == NULL || calls == NULL || starts == NULL) return set_err(CSGPU_E_ARG, "null argument");
+  for (int i = 0; i < 4; i++) seconds[i] = m->srv_seconds[i];
+  *calls = m->srv_calls;
+  *starts = m->srv_starts;
+  return CSGPU_OK;
+}
+
 extern "C" int csgpu_propagate_one_causes(const csgpu_model *cm, const csgpu_val *state, csgpu_node node,
                                           csgpu_val *state_out, csgpu_result *result, int32_t *trace, int32_t cap,
                                           int32_t *count) {
@@ -1695,6 +1885,7 @@ extern "C" int csgpu_propagate_one_causes(const csgpu_model *cm, const csgpu_val
     return set_err(CSGPU_E_ARG, "bad argument");
   if (!m->finalized) return set_err(CSGPU_E_STATE, "model is not finalized");
   if (!m->dense_waves) return set_err(CSGPU_E_LIMIT, "model does not qualify for the interval-only shaving kernel");
+  if (server_usable(m)) return server_call(m, state, node, state_out, result, trace, cap, count);
   if (m->trace_cap < cap) {
     if (m->h_trace != NULL) (void)hipHostFree(m->h_trace);
     m->h_trace = NULL;
@@ -1705,6 +1896,7 @@ extern "C" int csgpu_propagate_one_causes(const csgpu_model *cm, const csgpu_val
   const size_t nbytes = (size_t)m->host->n_vars * sizeof(cs_val);
   const size_t part = (nbytes + 63) & ~(size_t)63;
   node.parent = 0;
+  const double tl0 = srv_now();
   memcpy(m->h_one, state, nbytes);
   memcpy(m->h_one + part, &node, sizeof node);
   *m->h_trace_n = 0u;
@@ -1727,9 +1919,12 @@ extern "C" int csgpu_propagate_one_causes(const csgpu_model *cm, const csgpu_val
                    &nb_d, &d_batch, &csz, &tickets, &d_trace, &d_trace_n, &ucap };
   const size_t lds_trace = ((m->dense_bytes + 15) & ~(size_t)15) + CS_SHAVE_TRACE_LDS * 16;
   if (lds_trace > 160u * 1024u) return set_err(CSGPU_E_LIMIT, "no room in LDS for the trail next to the pair table");
+  const double tl1 = srv_now();
   HIP_TRY(hipLaunchKernel(ne_shave_trace_kernel(m->img->dense_width, n, slots), dim3(1), dim3((unsigned)(m->dense_waves * CS_WAVE)),
                           args, lds_trace, (hipStream_t)NULL));
+  const double tl2 = srv_now();
   { const int rcw = wait_null_stream(); if (rcw != CSGPU_OK) return rcw; }
+  const double tl3 = srv_now();
   memcpy(result, m->h_one + part + 64, sizeof *result);
   if (result->status >= 0) memcpy(state_out, m->h_one + part + 128, nbytes);
   const unsigned made = *m->h_trace_n;
@@ -1737,6 +1932,8 @@ extern "C" int csgpu_propagate_one_causes(const csgpu_model *cm, const csgpu_val
   unsigned kept = made < CS_SHAVE_TRACE_LDS ? made : CS_SHAVE_TRACE_LDS; /* what the kernel's LDS buffer holds */
   if (kept > (unsigned)cap) kept = (unsigned)cap;
   memcpy(trace, m->h_trace, (size_t)kept * 16);
+  m->srv_seconds[0] += tl1 - tl0; m->srv_seconds[1] += tl2 - tl1; m->srv_seconds[2] += tl3 - tl2; m->srv_seconds[3] += srv_now() - tl3;
+  m->srv_calls++;
   return CSGPU_OK;
 }
 
@@ -1744,6 +1941,8 @@ extern "C" int csgpu_propagate_one(const csgpu_model *m, const csgpu_val *state,
                                    csgpu_result *result) {
   if (m == NULL || state == NULL || state_out == NULL || result == NULL) return set_err(CSGPU_E_ARG, "null argument");
   if (!m->finalized) return set_err(CSGPU_E_STATE, "model is not finalized");
+  if ((m->kernel_choice == 0 || m->kernel_choice == 7) && m->dense_waves && server_usable(const_cast<csgpu_model *>(m)))
+    return server_call(const_cast<csgpu_model *>(m), state, node, state_out, result, NULL, 0, NULL);
   const size_t nbytes = (size_t)m->host->n_vars * sizeof(cs_val);
   const size_t part = (nbytes + 63) & ~(size_t)63;
   node.parent = 0;

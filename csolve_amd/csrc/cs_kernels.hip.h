@@ -1887,9 +1887,14 @@ __global__ __launch_bounds__(1024, 8) void cs_propagate_ne_packed(
 
 /* ---- full sweeps (root phase): one workgroup per instance ------------------------ */
 
+/* sequential != 0: the reference's own order -- ONE thread revises the clauses one after the other, in root-element
+ * order, every revision seeing what the ones before it left (propagate_wand, propagate.c:379-392, under the do-while
+ * of propagate(), 474-485): a sweep is then exactly a sweep of the reference, which matters when `max_rounds` cuts
+ * the iteration short of the fixpoint.  *converged (nullable) = the last sweep changed nothing. */
 __global__ __launch_bounds__(CS_BLOCK) void cs_propagate_sweeps(cs_tables T, const cs_val *__restrict__ states_in,
                                                                 cs_val *__restrict__ states_out,
-                                                                cs_node_out *__restrict__ results, int max_rounds) {
+                                                                cs_node_out *__restrict__ results, int max_rounds,
+                                                                int sequential, int *__restrict__ converged) {
   extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
   const int n = T.n_vars;
   cs_val *dom = (cs_val *)cs_lds;
@@ -1912,7 +1917,9 @@ __global__ __launch_bounds__(CS_BLOCK) void cs_propagate_sweeps(cs_tables T, con
   cx.revisions = 0;
   int rounds = 0;
   for (;;) {
-    for (int c = threadIdx.x; c < T.n_clauses && !cx.fail; c += blockDim.x) {
+    const int c_first = sequential ? (threadIdx.x == 0 ? 0 : T.n_clauses) : (int)threadIdx.x;
+    const int c_step = sequential ? 1 : (int)blockDim.x;
+    for (int c = c_first; c < T.n_clauses && !cx.fail; c += c_step) {
       const int4 rec = T.clause[c];
       if (rec.x == CS_CL_NE) {
         cs_ne_revise(cx, rec.y, rec.z, rec.w);
@@ -1950,6 +1957,7 @@ __global__ __launch_bounds__(CS_BLOCK) void cs_propagate_sweeps(cs_tables T, con
     r.revisions = (int)flags[3];
     r.rounds = rounds;
     results[inst] = r;
+    if (converged != nullptr) converged[inst] = flags[1] == 0u && flags[0] == 0u;
   }
 }
 

@@ -569,4 +569,143 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_shave(
 #endif
 }
 
+/* ---- the resident single-node server (the drop-in's calls) --------------------------------------------------------
+ * One propagate_clauses of the reference's driver is one node.  As a launch it costs what a launch costs: submit,
+ * dispatch, completion signal and the host's wait were 14 of the 19 us of a call.  The server is
+ * kernel 7's tracing variant as ONE resident wave on a mailbox in coherent host memory: the host writes the node record
+ * and the state, then the request number; the wave polls that word, runs the fixpoint, writes state, trail and result
+ * back and acknowledges with the same number.  No launch, no stream, no completion signal per call.
+ * The wave leaves when the host says so (`stop`) or after `idle_ticks` of the 100 MHz clock without a request (a
+ * process that exits without freeing its model must not leave a wave behind); `alive` tells the host, which starts
+ * a new one with the next call. */
+struct cs_mailbox_head {
+  unsigned req_seq; unsigned pad0[15];            /* written by the host, last */
+  unsigned ack_seq; unsigned alive; unsigned pad1[14]; /* written by the device */
+  unsigned stop; unsigned pad2[15];               /* written by the host */
+  cs_node_in node; unsigned want_trace; unsigned pad3[11];
+  cs_node_out result; unsigned trace_n; unsigned pad4[11];
+};
+
+template <typename E, int R, int SL>
+__global__ __launch_bounds__(1024) void cs_shave_server(int n, const E *__restrict__ tab_g, int slots, int dmin,
+                                                        const int *__restrict__ root_lo, const int *__restrict__ sym_off,
+                                                        cs_mailbox_head *box, unsigned long long *state_in /* [n] host */,
+                                                        unsigned long long *state_out /* [n] host */, int4 *trace /* host */,
+                                                        unsigned trace_cap, unsigned long long idle_ticks) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
+  typedef unsigned long long u64;
+  constexpr int W = CS_WAVE * R;
+  const int lane = threadIdx.x & (CS_WAVE - 1);
+  if (SL != 0) slots = SL;
+  {
+    const int vecs = (int)(((size_t)n * slots * W * sizeof(E)) / 16);
+    const uint4 *src = (const uint4 *)tab_g;
+    uint4 *dst = (uint4 *)cs_lds;
+    for (int i = threadIdx.x; i < vecs; i += blockDim.x) dst[i] = src[i];
+  }
+  int4 *s_trace = (int4 *)(cs_lds + ((((size_t)n * slots * W * sizeof(E)) + 15) & ~(size_t)15));
+  __syncthreads();
+  if (threadIdx.x >= CS_WAVE) return; /* the other waves only helped with the table */
+
+  cs_shave_core<E, R, SL, true> C;
+  C.s_tab = (const E *)cs_lds; C.slots = slots; C.lane = lane; C.s_trace = s_trace; C.tcount = 0u;
+  int b0[R];
+  bool live[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const int v = lane + r * CS_WAVE;
+    live[r] = v < n;
+    const int vc = live[r] ? v : n - 1;
+    b0[r] = live[r] ? root_lo[vc] : 0;
+    C.b0[r] = b0[r];
+    C.kb[r] = b0[r] - dmin;
+    C.deg[r] = live[r] ? sym_off[vc + 1] - sym_off[vc] : 0;
+    C.livemask[r] = __ballot(live[r]);
+  }
+  unsigned last = __hip_atomic_load(&box->ack_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (lane == 0) __hip_atomic_store(&box->alive, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  u64 idle_since = __builtin_amdgcn_s_memrealtime();
+  for (;;) {
+    const unsigned seq = __hip_atomic_load(&box->req_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (seq == last) {
+      if (__hip_atomic_load(&box->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) break;
+      if (__builtin_amdgcn_s_memrealtime() - idle_since > idle_ticks) break;
+      __builtin_amdgcn_s_sleep(2);
+      continue;
+    }
+    /* the request: node record and state (coherent host memory: system-scope loads) */
+    const int nvar = (int)__hip_atomic_load((unsigned *)&box->node.var, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const int nlo = (int)__hip_atomic_load((unsigned *)&box->node.lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const int nhi = (int)__hip_atomic_load((unsigned *)&box->node.hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned want_trace = __hip_atomic_load(&box->want_trace, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    int rlo[R], rhi[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const int v = lane + r * CS_WAVE;
+      const u64 e = __hip_atomic_load(&state_in[live[r] ? v : n - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      rlo[r] = live[r] ? (int)(unsigned)e - b0[r] : 0;
+      rhi[r] = live[r] ? (int)(unsigned)(e >> 32) - b0[r] : 0;
+    }
+    u64 pushed[R], push[R], dl[R], dh[R], val[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      pushed[r] = nvar < 0 ? ~C.livemask[r] : __ballot(rlo[r] == rhi[r]);
+      dl[r] = 0ull; dh[r] = 0ull;
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      if (nvar >= 0 && (nvar >> 6) == r) {
+        const u64 bit = 1ull << (nvar & 63); /* a scalar shift */
+        if (lane == (nvar & 63)) { rlo[r] = nlo - b0[r]; rhi[r] = nhi - b0[r]; }
+        pushed[r] &= ~bit;
+        if (nlo != nhi) { dl[r] |= bit; dh[r] |= bit; }
+      }
+    }
+    int lo0[R], hi0[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      lo0[r] = rlo[r]; hi0[r] = rhi[r];
+      val[r] = __ballot(rlo[r] == rhi[r]) & C.livemask[r];
+      push[r] = val[r] & ~pushed[r];
+    }
+    C.tcount = 0u;
+    int rounds = 0, revisions = 0;
+    const int fail_var = C.fixpoint(rlo, rhi, pushed, push, dl, dh, val, rounds, revisions);
+    if (rounds != 0) __builtin_amdgcn_s_setprio(0);
+    const int failed = fail_var >= 0;
+    int open_vars = 0, shaved = 0;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      open_vars += __popcll(__ballot(rlo[r] != rhi[r]));
+      shaved += (rlo[r] - lo0[r]) + (hi0[r] - rhi[r]);
+    }
+    const int props = cs_wave_sum(shaved);
+    /* the answer: state, trail, result -- then the acknowledgement behind a system-scope release */
+    if (!failed) {
+#pragma unroll
+      for (int r = 0; r < R; r++)
+        if (live[r]) {
+          const u64 e = (u64)(unsigned)(rlo[r] + b0[r]) | ((u64)(unsigned)(rhi[r] + b0[r]) << 32);
+          __hip_atomic_store(&state_out[lane + r * CS_WAVE], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    if (want_trace != 0u) {
+      const unsigned keep = C.tcount < CS_SHAVE_TRACE_LDS ? C.tcount : CS_SHAVE_TRACE_LDS;
+      for (unsigned i = lane; i < keep && i < trace_cap; i += CS_WAVE) trace[i] = s_trace[i];
+    }
+    if (lane == 0) {
+      box->result.status = failed ? -1 : open_vars;
+      box->result.props = props;
+      box->result.revisions = revisions;
+      box->result.rounds = failed ? fail_var : rounds;
+      box->trace_n = C.tcount;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    if (lane == 0) __hip_atomic_store(&box->ack_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    last = seq;
+    idle_since = __builtin_amdgcn_s_memrealtime();
+  }
+  if (lane == 0) __hip_atomic_store(&box->alive, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 #endif

@@ -350,6 +350,17 @@ int csgpu_propagate_one_traced(const csgpu_model *m, const csgpu_val *state, csg
  * variables on the way from the assignment to a failure (propagate_term_recurse, propagate.c:44-54). */
 int csgpu_propagate_one_causes(const csgpu_model *m, const csgpu_val *state, csgpu_node node, csgpu_val *state_out,
                                csgpu_result *result, int32_t *trace, int32_t cap, int32_t *count);
+/* THE RESIDENT SERVER behind the two entries above.  One propagate_clauses of the reference's driver (csolve.c:247-261)
+ * is one node; as a kernel launch it costs launch submit + dispatch + completion signal + the host's wait, 14 of the
+ * 19 us of a call.  For the models of kernel 7 (pure != networks of at most 256 variables) csgpu_propagate_one and
+ * csgpu_propagate_one_causes therefore talk to ONE resident wavefront through a mailbox in coherent host memory: the
+ * host writes node record and state, then a request number; the wave polls it, runs the fixpoint, writes state, trail
+ * and result back and acknowledges.  The wave leaves when the model is freed or after 2 ms without a request
+ * (CSGPU_SERVER_IDLE_US) and is started again by the next call; CSGPU_SERVER=0 keeps the launch per call.  Results are
+ * those of kernel 7 (same code).  csgpu_debug_one_timing: where the host's time of these calls went -- seconds[0..3] =
+ * {copy in, ring + wait, copy out, server (re)starts} with the server, {copy in, launch submit, wait for completion,
+ * copy out} without; calls made, servers started. */
+int csgpu_debug_one_timing(const csgpu_model *m, double *seconds, uint64_t *calls, uint64_t *starts);
 
 #ifdef __cplusplus
 }

@@ -517,7 +517,7 @@ int main(int argc, char **argv) {
                        STRATEGY_COMPUTE_WEIGHTS_DEFAULT, STRATEGY_RESTART_FREQUENCY_DEFAULT,
                        STRATEGY_ORDER_DEFAULT, TIME_MAX_DEFAULT };
   const char *cmd = argv[1], *path = argv[2];
-  int first_opt = strcmp(cmd, "solve") == 0 ? 3 : (strcmp(cmd, "model") == 0 ? 4 : (strcmp(cmd, "bench") == 0 ? 5 : 6));
+  int first_opt = strcmp(cmd, "solve") == 0 ? 3 : (strcmp(cmd, "model") == 0 || strcmp(cmd, "rootlimit") == 0 ? 4 : (strcmp(cmd, "bench") == 0 ? 5 : 6));
   for (int i = first_opt; i + 1 < argc; i += 2) {
     if (strcmp(argv[i], "-c") == 0) o.conflicts = parse_bool(argv[i + 1]);
     else if (strcmp(argv[i], "-f") == 0) o.prefer_failing = parse_bool(argv[i + 1]);
@@ -537,6 +537,25 @@ int main(int argc, char **argv) {
   if (strcmp(cmd, "walk") == 0) {
     if (argc < 6) { fprintf(stderr, "usage: csolve_ref walk <file> <seed> <count> <out>\n"); return 2; }
     return cmd_walk(path, strtoull(argv[3], NULL, 10), strtol(argv[4], NULL, 10), argv[5]);
+  }
+
+  if (strcmp(cmd, "rootlimit") == 0) {
+    /* csolve_ref rootlimit <file> <limit>: the front end, then ONE call propagate(root, limit) (propagate.c:474-485) on
+     * the raw root -- no normalisation -- and the variables' domains after it (golden vectors of the limit's semantics) */
+    if (argc < 4) { fprintf(stderr, "usage: csolve_ref rootlimit <file> <limit>\n"); return 2; }
+    char *text = slurp(path);
+    char err[200];
+    cs_builder b = { NULL, r_num, r_ident, r_unary, r_binary, r_wand, r_weigh, r_objective, r_constraint };
+    if (cs_parse_text(text, &b, err, sizeof err) != 0) { fprintf(stderr, "csolve_ref: error: %s\n", err); return 1; }
+    free(text);
+    const size_t nv = var_count();
+    const prop_result_t p = propagate(root_wand, (size_t)strtoull(argv[3], NULL, 10));
+    struct env_t *ev = env_generate();
+    printf("@ROOT {\"status\": %d, \"domains\": {", p == PROP_ERROR ? -1 : (int)p);
+    for (size_t v = 0; v < nv; v++)
+      printf("%s\"%s\": [%d, %d]", v ? ", " : "", ev[v].key, ev[v].val->constr.term.val.lo, ev[v].val->constr.term.val.hi);
+    printf("}}\n");
+    return 0;
   }
 
   size_t size;

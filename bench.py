@@ -821,15 +821,20 @@ def end_to_end_record():
                     d = json.loads(m.group(1))
                     r["device_call_seconds"] = d["device_call_seconds"]
                     r["shim_host_seconds"] = d["shim_host_seconds"]
-                    r["attach_seconds"] = d["attach_seconds"]
+                    r["attach_seconds"] = d["attach_seconds"]  # building the device model: contains the HIP runtime's start-up
+                    r["root_seconds_without_attach"] = r["root_seconds"] - d["attach_seconds"]
+                    r["call_us_median"] = d.get("call_us_median")
+                    r["call_us_p90"] = d.get("call_us_p90")
                 r["us_per_call"] = 1e6 * st["solve_seconds"] / max(1, st["calls"])
                 rec[name] = r
             rec["solve_speedup"] = rec["cpu_reference"]["solve_seconds"] / rec["reference_driver_on_gpu_propagator"]["solve_seconds"]
             rec["per_call_speedup"] = rec["cpu_reference"]["us_per_call"] / rec["reference_driver_on_gpu_propagator"]["us_per_call"]
             out[f"queens{nq}"] = rec
     out["flags"] = "-c false (defaults otherwise: -f true -r 100 -o none)"
-    out["note"] = ("solve_seconds = the reference's solve() only; root_seconds (parse + root phase; on the GPU build it "
-                   "contains the HIP start-up) is listed separately")
+    out["note"] = ("solve_seconds = the reference's solve() only; root_seconds (parse + root phase) is listed separately: on the "
+                   "GPU build it contains attach_seconds (device model + HIP runtime start-up + start of the resident "
+                   "single-node server); root_seconds_without_attach is the rest.  Every propagate_clauses of the driver is "
+                   "one request to the resident server (include/csolve_gpu.h), no kernel launch")
     return out
 
 

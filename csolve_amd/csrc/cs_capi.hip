@@ -220,9 +220,20 @@ extern "C" int csgpu_model_from_host(cs_model *host, int lists_final, int domain
 extern "C" cs_model *csgpu_model_host(csgpu_model *m) { return m ? m->host : NULL; }
 
 static void server_stop(csgpu_model *m);
+/* Models whose resident server may be running.  hipFree, hipDeviceSynchronize and friends wait for EVERY stream of the
+ * device, the server's included -- they would sit out its idle time-out (2 ms) each.  Entry points that allocate, free
+ * or synchronise device-wide therefore ask the servers of this process to leave first (a flag in the mailbox: the wave
+ * is gone within microseconds); the next single-node call starts one again. */
+static csgpu_model *g_srv_models[16];
+static void quiesce_servers(void) {
+  for (int i = 0; i < 16; i++)
+    if (g_srv_models[i] != NULL) server_stop(g_srv_models[i]);
+}
 
 static void free_device(csgpu_model *m) {
-  server_stop(m); /* before anything is freed: the resident wave reads the tables */
+  quiesce_servers(); /* before anything is freed: this model's resident wave reads the tables, and hipFree waits for all of them */
+  for (int i = 0; i < 16; i++)
+    if (g_srv_models[i] == m) g_srv_models[i] = NULL;
   if (m->h_box != NULL) (void)hipHostFree(m->h_box);
   m->h_box = NULL;
   if (m->srv_stream != NULL) (void)hipStreamDestroy(m->srv_stream);
@@ -384,6 +395,7 @@ extern "C" int csgpu_model_root_propagate(csgpu_model *m, int32_t *status) {
 
 extern "C" int csgpu_model_root_propagate_limit(csgpu_model *m, int64_t limit, int32_t *status, int32_t *rounds) {
   if (m == NULL || status == NULL) return set_err(CSGPU_E_ARG, "null argument");
+  quiesce_servers();
   cs_model *h = m->host;
   if (h->root < 0) return set_err(CSGPU_E_STATE, "model has no root");
   if (!m->from_dump && cs_model_index(h) != 0) return set_err(CSGPU_E_ARG, "%s", h->err);
@@ -471,6 +483,7 @@ extern "C" int csgpu_model_add_conflict(csgpu_model *m, int32_t count, const int
 
 extern "C" int csgpu_model_eval_clauses_host(csgpu_model *m, csgpu_val *vals) {
   if (m == NULL || vals == NULL) return set_err(CSGPU_E_ARG, "null argument");
+  quiesce_servers();
   cs_model *h = m->host;
   if (h->root < 0) return set_err(CSGPU_E_STATE, "model has no root");
   if (!m->from_dump && cs_model_index(h) != 0) return set_err(CSGPU_E_ARG, "%s", h->err);
@@ -1772,6 +1785,8 @@ static int server_usable(csgpu_model *m) {
   }
   memset(m->h_box, 0, total);
   m->srv_seq = 0;
+  for (int i = 0; i < 16; i++)
+    if (g_srv_models[i] == NULL) { g_srv_models[i] = m; break; }
   return 1;
 }
 
@@ -1865,6 +1880,12 @@ static int server_call(csgpu_model *m, const csgpu_val *state, csgpu_node node, 
   m->srv_seconds[3] += t_start;
   m->srv_calls++;
   return CSGPU_OK;
+}
+
+extern "C" int csgpu_internal_server_warm(csgpu_model *m) {
+  if (m == NULL || !m->finalized || !server_usable(m)) return CSGPU_OK;
+  if (__atomic_load_n(&srv_box(m)->alive, __ATOMIC_ACQUIRE) != 0u) return CSGPU_OK;
+  return server_start(m);
 }
 
 /* where the time of the single-node calls went: seconds[0..3] = host copy in, ring + wait, copy out, server (re)starts;

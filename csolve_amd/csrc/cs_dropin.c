@@ -255,12 +255,14 @@ uint64_t csolve_dropin_chain_bumps(void) { return g_chain_bumps; }
 /* where the shim's time goes: [0] attach (flatten + finalize + upload), [1] inside the device calls of
  * propagate_clauses, [2] the rest of propagate_clauses (state marshalling, bind() replay) */
 static double g_seconds[3];
+static double g_eval_seconds; /* inside the eval entry points (update_solution's root evaluation, single operators) */
 static double now_s(void) {
   struct timespec t;
   clock_gettime(CLOCK_MONOTONIC, &t);
   return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
 }
 void csolve_dropin_seconds(double out[3]) { memcpy(out, g_seconds, sizeof g_seconds); }
+double csolve_dropin_eval_seconds(void) { return g_eval_seconds; }
 
 /* per-call device times of propagate_clauses (the first 2^20 calls): where a search's time goes call by call */
 #define CS_CALL_TIMES (1 << 20)
@@ -450,6 +452,8 @@ static int attach(struct env_t *env, size_t size, struct constr_t *root, int at_
 
   if (csgpu_model_from_host(f.m, 1, at_root || snapped, &g_model) != CSGPU_OK) fatal_gpu("attach");
   if (csgpu_model_finalize(g_model) != CSGPU_OK) fatal_gpu("attach");
+  /* every propagate_clauses of the driver is a single-node call: have the resident server up before the first one */
+  if (csgpu_internal_server_warm(g_model) != CSGPU_OK) fatal_gpu("attach");
   g_env = env;
   g_size = size;
   g_root = root;
@@ -971,7 +975,15 @@ static void eval_subtree_into_cache(const struct constr_t *top) {
   free(vals); free(kids); free(kid_of); free(list);
 }
 
+static struct val_t eval_tree_timed(const struct constr_t *constr);
 static struct val_t eval_tree(const struct constr_t *constr) {
+  const double t0 = now_s();
+  const struct val_t v = eval_tree_timed(constr);
+  g_eval_seconds += now_s() - t0;
+  return v;
+}
+
+static struct val_t eval_tree_timed(const struct constr_t *constr) {
   struct val_t out = { 0, 1 };
   g_calls[2]++;
   if (g_model != NULL && constr == g_root) {

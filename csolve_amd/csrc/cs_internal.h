@@ -36,6 +36,11 @@ const int32_t *csgpu_internal_root_lo(const csgpu_model *m);
 int csgpu_internal_eval_list(const csgpu_model *m, const csgpu_val *d_states, const int32_t *d_list,
                              const uint64_t *d_count, int64_t bound, int32_t *d_truth, void *stream);
 
+/* start the resident single-node server of this model now (csolve_gpu.h, csgpu_debug_one_timing) instead of with the
+ * first single-node call: the drop-in does it when it attaches, so that the start (stream, mailbox, code load, launch)
+ * is part of the set-up and not of the driver's first propagate_clauses.  No-op for models without a server. */
+int csgpu_internal_server_warm(csgpu_model *m);
+
 /* ---- one level of the search tree in one launch (cs_step.hip.h): branch + fixpoints of the children + store ---- */
 typedef struct csgpu_step_launch {
   const csgpu_val *pool;  /* parents (engine rows): rows first_row .. first_row + parents - 1, drawn from the top down */

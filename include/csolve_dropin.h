@@ -120,6 +120,8 @@ void csolve_dropin_sibling_counters(uint64_t out[2]);
 void csolve_dropin_learning_counters(uint64_t out[2]);
 /* seconds spent so far in [0] attach, [1] the device calls of propagate_clauses, [2] the rest of propagate_clauses */
 void csolve_dropin_seconds(double out[3]);
+/* seconds spent inside the eval entry points (update_solution evaluates the root once per complete assignment) */
+double csolve_dropin_eval_seconds(void);
 /* device time of the propagate_clauses calls so far, in microseconds: { first call, median, 90th percentile, maximum } */
 void csolve_dropin_call_times(double out[4]);
 

@@ -597,6 +597,8 @@ int main(int argc, char **argv) {
       extern void csolve_dropin_learning_counters(uint64_t out[2]);
       uint64_t lc[2];
       csolve_dropin_learning_counters(lc);
+      extern double csolve_dropin_eval_seconds(void);
+      printf("@DROPIN_EVAL {\"eval_seconds\": %.6f}\n", csolve_dropin_eval_seconds());
       printf("@DROPIN {\"propagate_clauses\": %lu, \"propagate\": %lu, \"eval\": %lu, \"single_op\": %lu, "
              "\"sibling_batches\": %lu, \"served_from_batch\": %lu, \"conflicts_offered\": %lu, \"reattached\": %lu, "
              "\"attach_seconds\": %.6f, \"device_call_seconds\": %.6f, \"shim_host_seconds\": %.6f, "

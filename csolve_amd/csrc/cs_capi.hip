@@ -220,6 +220,7 @@ extern "C" int csgpu_model_from_host(cs_model *host, int lists_final, int domain
 extern "C" cs_model *csgpu_model_host(csgpu_model *m) { return m ? m->host : NULL; }
 
 static void server_stop(csgpu_model *m);
+static void server_reap(csgpu_model *m);
 /* Models whose resident server may be running.  hipFree, hipDeviceSynchronize and friends wait for EVERY stream of the
  * device, the server's included -- they would sit out its idle time-out (2 ms) each.  Entry points that allocate, free
  * or synchronise device-wide therefore ask the servers of this process to leave first (a flag in the mailbox: the wave
@@ -1793,7 +1794,7 @@ static int server_usable(csgpu_model *m) {
 /* start a resident wave (none is alive) and wait until it says so */
 static int server_start(csgpu_model *m) {
   cs_mailbox_head *box = srv_box(m);
-  if (m->srv_launched) HIP_TRY(hipStreamSynchronize(m->srv_stream)); /* the previous one has left (alive == 0): reap it */
+  if (m->srv_launched) server_reap(m); /* the previous one has left (alive == 0): reap it */
   void *dev = NULL;
   HIP_TRY(hipHostGetDevicePointer(&dev, m->h_box, 0));
   cs_mailbox_head *d_box = (cs_mailbox_head *)dev;
@@ -1821,11 +1822,22 @@ static int server_start(csgpu_model *m) {
   return CSGPU_OK;
 }
 
+/* wait for the server's stream by polling (hipStreamSynchronize on a kernel that has run for long sleeps in the kernel
+ * driver and is woken milliseconds late: the solution check of a queens-64 search took 9 ms instead of 2) */
+static void server_reap(csgpu_model *m) {
+  const double t0 = srv_now();
+  for (;;) {
+    const hipError_t e = hipStreamQuery(m->srv_stream);
+    if (e != hipErrorNotReady) break;
+    if (srv_now() - t0 > 5.0) { (void)hipStreamSynchronize(m->srv_stream); break; }
+  }
+}
+
 static void server_stop(csgpu_model *m) {
   if (m->h_box == NULL || !m->srv_launched) return;
   cs_mailbox_head *box = srv_box(m);
   __atomic_store_n(&box->stop, 1u, __ATOMIC_RELEASE);
-  (void)hipStreamSynchronize(m->srv_stream);
+  server_reap(m);
   __atomic_store_n(&box->stop, 0u, __ATOMIC_RELEASE);
   m->srv_launched = 0;
 }

@@ -144,6 +144,7 @@ def test_learnt_conflict_clauses_against_the_oracle(tmp_path):
     to a finalized model (csgpu_model_add_conflict); the general kernel and the clause-resident one agree"""
     from csolve_amd.solver import Model
     from oracle.cs_oracle import Model as OModel, Oracle
+    report = []
     for seed in range(4):
         rng = np.random.default_rng(100 + seed)
         n = 24 + 8 * seed
@@ -195,7 +196,7 @@ def test_learnt_conflict_clauses_against_the_oracle(tmp_path):
                 out, res = gm.propagate(d_par, d_nodes)
                 torch.cuda.synchronize()
                 out, res = out.cpu().numpy(), res.cpu().numpy()
-                compared = 0
+                compared = skipped_ref = skipped_dev = 0
                 for i, (st, exp) in enumerate(want):
                     # propagate_confl infers but never fails (propagate.c:461-471: with every element at its conflict
                     # value it answers PROP_NONE), so when two clauses push one variable opposite ways the outcome
@@ -203,8 +204,10 @@ def test_learnt_conflict_clauses_against_the_oracle(tmp_path):
                     # violates one of these (random, not implied) conflicts, the device's rounds see the bounds cross.
                     # Such instances have no order-independent answer and are left out.
                     if st >= 0 and any(all(exp[v, 0] == exp[v, 1] == val for v, val in c) for c in confl):
+                        skipped_ref += 1  # the reference's own end state violates one of the (random) conflicts
                         continue
                     if res[i, 0] >= 0 and any(all(out[i][v, 0] == out[i][v, 1] == val for v, val in c) for c in confl):
+                        skipped_dev += 1
                         continue
                     compared += 1
                     assert (st < 0) == (res[i, 0] < 0), (seed, k, i, nodes[i].tolist(), st, res[i].tolist())
@@ -212,6 +215,24 @@ def test_learnt_conflict_clauses_against_the_oracle(tmp_path):
                         assert (out[i] == exp).all(), (seed, k, i)
                         assert res[i, 1] == st, (seed, k, i, "PROPS")
                 assert compared > 400, compared
+                assert compared + skipped_ref + skipped_dev == len(want)
+                # how many instances have no order-independent answer is part of the record, not hidden
+                report.append({"seed": int(seed), "kernel": k, "model": "clauses at build time" if gm is with_clauses else "added after finalize",
+                               "instances": len(want), "compared": compared, "skipped_reference_state_violates_a_conflict": skipped_ref,
+                               "skipped_device_state_violates_a_conflict": skipped_dev})
+                assert skipped_dev == 0, "a consistent device state never violates a learnt clause: the rounds see the bounds cross"
+
+    # the count of left-out instances is part of the evidence (profiles/ keeps the copy of a GPU run)
+    import json
+    import os
+    out_dir = os.environ.get("CSOLVE_REPORT_DIR")
+    print("conflict-clause parity:", json.dumps(report))
+    if out_dir:
+        os.makedirs(out_dir, exist_ok=True)
+        json.dump({"test": "tests/test_gpu_ops.py::test_learnt_conflict_clauses_against_the_oracle",
+                   "note": "instances whose reference end state violates one of the random conflict clauses have no "
+                           "order-independent answer (propagate_confl never fails, propagate.c:461-471) and are left out",
+                   "runs": report}, open(os.path.join(out_dir, "conflict_clause_parity.json"), "w"), indent=1)
 
 
 def test_trail_of_one_node(tmp_path):

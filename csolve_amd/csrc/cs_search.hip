@@ -1013,6 +1013,12 @@ extern "C" int csgpu_search_create(const csgpu_model *m, int64_t pool_capacity, 
   ALLOC(s->pool, row * (size_t)s->cap);
   s->fw = s->obj_var < 0 ? csgpu_model_forbidden_words(m) : 0;
   {
+    /* CSGPU_SEARCH_SETS=0: interval rows only in the pool of the separate-kernel path too (the fixpoints then run on
+     * kernel 7 / kernel 5's rebuild entry, and no child is cut without a launch) */
+    const char *es = getenv("CSGPU_SEARCH_SETS");
+    if (es != NULL && es[0] == '0') s->fw = 0;
+  }
+  {
     const char *ef = getenv("CSGPU_SEARCH_FUSED"), *ev = getenv("CSGPU_SEARCH_EVAL");
     s->fused = s->objective == CS_OBJ_ALL && csgpu_internal_step_kind(m) != 0 && !(ef != NULL && ef[0] == '0') &&
                !(ev != NULL && ev[0] == '1');

@@ -32,7 +32,34 @@ enum { C_SURVIVORS = 0, C_COMPLETE, C_CUTS, C_PROPS, C_REVS, C_TOTAL_CHILDREN, C
 struct cs_holes {
   const unsigned long long *pool_forb; /* nullptr: every value of the interval becomes a launched child */
   const int *root_lo;
+  /* the branching rule (strategy_var_cmp, reference src/strategy.c:79-121): which open variable comes first --
+   * order 0 none, 1 smallest domain (the default), 2 largest domain, 3 smallest value, 4 largest value -- and, with
+   * `prio` != nullptr (-f true: prefer failing), among equals the one with the highest failure count; then the
+   * lowest index.  What the reference keeps in a heap is the minimum of this key over the open variables. */
+  int order;
+  const int *prio;
 };
+
+/* the part of the branching key that the state decides: smaller comes first */
+__device__ __forceinline__ unsigned cs_order_key(int order, cs_val d) {
+  switch (order) {
+  case 0: return 0u;
+  case 2: return 0xffffffffu - (unsigned)((long long)d.hi - (long long)d.lo);
+  case 3: return (unsigned)d.lo ^ 0x80000000u;
+  case 4: return 0x7fffffffu - (unsigned)d.hi + 0x80000000u; /* INT_MAX - hi, as an unsigned rank */
+  default: return (unsigned)((long long)d.hi - (long long)d.lo); /* width - 1 */
+  }
+}
+/* ... and the whole key: state part, then failure count (higher first), then index */
+__device__ __forceinline__ unsigned long long cs_branch_key(const cs_holes &H, cs_val d, int v) {
+  unsigned pk = 0u;
+  if (H.prio != nullptr) {
+    int p = H.prio[v] + 32768;
+    p = p < 0 ? 0 : (p > 65535 ? 65535 : p);
+    pk = 65535u - (unsigned)p;
+  }
+  return ((unsigned long long)cs_order_key(H.order, d) << 32) | ((unsigned long long)pk << 16) | (unsigned long long)(unsigned)(v & 0xffff);
+}
 
 /* what the branching step decides for a parent and the emitting step needs (32 bytes per parent) */
 struct cs_choice {
@@ -105,6 +132,9 @@ struct csgpu_search {
   uint64_t *d_wstat, *d_step_out, *h_step_out; /* h: pinned */
   double surv_per_parent;       /* recent survivors per parent (sizes the next frontier) */
   uint64_t stored_seen;         /* rows in the solution store after the last iteration */
+  /* the reference's strategy options (main.c:51-130): -o order, -f prefer failing, restart on a better solution */
+  int order, prefer_failing, restart_on_improvement, fail_var_known;
+  int *d_prio; /* [n] failure counts (prefer failing) */
   int burst_off;       /* CSGPU_SEARCH_BURST=0: every iteration driven from the host */
   int eval_always;     /* CSGPU_SEARCH_EVAL=1: complete children of pure != networks are evaluated all the same (tests) */
   int graph_off;       /* CSGPU_SEARCH_GRAPH=0: the launches of a burst enqueued one by one */
@@ -160,15 +190,13 @@ __device__ __forceinline__ cs_choice cs_branch_seg(const cs_val *__restrict__ ro
         my_forb = H.pool_forb[(size_t)row_index * n + sl];
         my_root = H.root_lo[sl];
       }
-      if (mine.lo != mine.hi)
-        best = ((unsigned long long)((long long)mine.hi - (long long)mine.lo) << 32) | (unsigned)sl;
+      if (mine.lo != mine.hi) best = cs_branch_key(H, mine, sl);
     }
   } else {
     for (int v = sl; v < n; v += S) {
       const cs_val d = row[v];
       if (d.lo != d.hi) {
-        const unsigned long long w = (unsigned long long)((long long)d.hi - (long long)d.lo);
-        const unsigned long long key = (w << 32) | (unsigned)v;
+        const unsigned long long key = cs_branch_key(H, d, v);
         best = key < best ? key : best;
       }
     }
@@ -180,7 +208,7 @@ __device__ __forceinline__ cs_choice cs_branch_seg(const cs_val *__restrict__ ro
   cs_choice c;
   c.var = -1; c.lo = 0; c.hi = 0; c.count = 0; c.a_lo = 0u; c.a_hi = 0u; c.holes = 0; c.skipped = 0;
   if (best == ~0ull) return c;
-  const int var = (int)(best & 0xffffffffu);
+  const int var = (int)(best & 0xffffu);
   cs_val d;
   unsigned long long forb = 0ull;
   int root = 0;
@@ -547,6 +575,28 @@ __global__ __launch_bounds__(SB) void cs_classify_assign(const csgpu_result *__r
   if (i < children) {
     if (surv) surv_list[surv_off[blockIdx.x] + s_surv[t] - 1] = i; /* survivor k goes to pool row new_top + k */
     if (comp) complete_list[comp_off[blockIdx.x] + s_comp[t] - 1] = i;
+  }
+}
+
+/* -f true (prefer failing): the failure counts the branching rule looks at.  What the reference does per node
+ * (csolve.c:455-465: the branching variable's prio-- when its assignment holds, prio++ when it fails;
+ * propagate_term_confl, propagate.c:33-41: prio++ of the variable whose domain emptied), for a whole batch of children.
+ * The reference's further bumps along its recursion stack (propagate.c:44-54) follow its depth-first order and have
+ * no counterpart in a batch.  fail_var_known: the fixpoint kernel reports the emptied variable in result.rounds. */
+__global__ __launch_bounds__(SB) void cs_prio_update(const csgpu_result *__restrict__ res, const csgpu_node *__restrict__ nodes,
+                                                     int children, const unsigned long long *__restrict__ children_dev,
+                                                     int n, int fail_var_known, int *__restrict__ prio) {
+  if (children_dev != nullptr && (long long)*children_dev < (long long)children) children = (int)*children_dev;
+  const int i = blockIdx.x * SB + threadIdx.x;
+  if (i >= children) return;
+  const csgpu_result r = res[i];
+  const int v = nodes[i].var;
+  if (v < 0 || v >= n) return;
+  if (r.status >= 0) {
+    atomicSub(&prio[v], 1);
+  } else {
+    atomicAdd(&prio[v], 1);
+    if (fail_var_known && r.rounds >= 0 && r.rounds < n && r.rounds != v) atomicAdd(&prio[r.rounds], 1);
   }
 }
 
@@ -948,6 +998,7 @@ extern "C" void csgpu_search_free(csgpu_search *s) {
   (void)hipFree(s->seed);
   (void)hipFree(s->d_best_solution);
   (void)hipFree(s->d_burst);
+  (void)hipFree(s->d_prio);
   (void)hipFree(s->d_fill); (void)hipFree(s->d_ticket); (void)hipFree(s->d_wstat); (void)hipFree(s->d_step_out);
   if (s->h_step_out) (void)hipHostFree(s->h_step_out);
   if (s->h_burst) (void)hipHostFree(s->h_burst);
@@ -1081,6 +1132,9 @@ extern "C" int csgpu_search_create(const csgpu_model *m, int64_t pool_capacity, 
 #undef ALLOC
   HIP_OK(hipMemset(s->d_counters, 0, sizeof(unsigned long long) * C_COUNT));
   HIP_OK(hipMemcpy(s->d_best, &s->st.best, sizeof(int), hipMemcpyHostToDevice));
+  s->order = 1;
+  s->holes.order = 1;
+  s->holes.prio = NULL;
   s->holes.pool_forb = NULL;
   s->holes.root_lo = csgpu_internal_root_lo(m);
   {
@@ -1148,7 +1202,7 @@ static int search_put(csgpu_search *s, const csgpu_val *d_states, int64_t count)
                        (size_t)k * s->n * s->fw * 8, hipMemcpyDeviceToDevice));
     }
   }
-  if (count > 0 && s->restart_base > 0 && !s->st.iterations) {
+  if (count > 0 && (s->restart_base > 0 || s->restart_on_improvement) && !s->st.iterations) {
     /* remember what the search was started from (only states put before the first iteration) */
     if (s->seed_count + count > s->seed_cap) {
       const int64_t cap = (s->seed_count + count) * 2;
@@ -1186,6 +1240,7 @@ extern "C" int csgpu_search_reset(csgpu_search *s) {
   s->pending_complete = 0;
   s->surv_per_parent = (double)s->max_width;
   s->stored_seen = 0;
+  if (s->d_prio != NULL) HIP_OK(hipMemset(s->d_prio, 0, sizeof(int) * (size_t)s->n));
   HIP_OK(hipMemset(s->d_counters, 0, sizeof(unsigned long long) * C_COUNT));
   HIP_OK(hipMemcpy(s->d_best, &s->st.best, sizeof(int), hipMemcpyHostToDevice));
   return CSGPU_OK;
@@ -1207,6 +1262,43 @@ extern "C" int csgpu_search_put_host(csgpu_search *s, const csgpu_val *states, i
 extern "C" int csgpu_search_set_restart(csgpu_search *s, int64_t iterations) {
   if (s == NULL || iterations < 0) return fail(CSGPU_E_ARG, "bad argument");
   s->restart_base = s->objective == CS_OBJ_ANY ? iterations : 0;
+  return CSGPU_OK;
+}
+
+extern "C" int csgpu_search_set_strategy(csgpu_search *s, int order, int prefer_failing) {
+  if (s == NULL || order < 0 || order > 4) return fail(CSGPU_E_ARG, "bad argument");
+  if (hipSetDevice(s->device) != hipSuccess) return fail(CSGPU_E_HIP, "hipSetDevice");
+  if (s->top != 0 || s->st.iterations != 0) return fail(CSGPU_E_STATE, "the strategy is set before the first state is put");
+  const int is_default = order == 1 && !prefer_failing;
+  if (!is_default) {
+    /* the level kernels and the cut of children by the parent's own set implement the default rule only; a count of
+     * failures needs the emptied variable of a failing child, which the interval kernels report */
+    s->fused = 0;
+    s->fw = 0;
+    s->holes.pool_forb = NULL;
+  }
+  s->order = order;
+  s->prefer_failing = prefer_failing != 0;
+  s->holes.order = order;
+  s->holes.prio = NULL;
+  if (s->prefer_failing) {
+    if (s->d_prio == NULL) HIP_OK(hipMalloc((void **)&s->d_prio, sizeof(int) * (size_t)s->n));
+    HIP_OK(hipMemset(s->d_prio, 0, sizeof(int) * (size_t)s->n));
+    s->holes.prio = s->d_prio;
+    const int k = csgpu_model_get_kernel(s->m);
+    s->fail_var_known = k == 1 || k == 6 || k == 7;
+  }
+  if (s->burst_exec != NULL) { /* the graph holds the old rule */
+    (void)hipGraphExecDestroy(s->burst_exec);
+    s->burst_exec = NULL;
+  }
+  return CSGPU_OK;
+}
+
+extern "C" int csgpu_search_set_restart_on_improvement(csgpu_search *s, int on) {
+  if (s == NULL) return fail(CSGPU_E_ARG, "bad argument");
+  if (s->top != 0 || s->st.iterations != 0) return fail(CSGPU_E_STATE, "set before the first state is put");
+  s->restart_on_improvement = on != 0 && (s->objective == CS_OBJ_MIN || s->objective == CS_OBJ_MAX);
   return CSGPU_OK;
 }
 
@@ -1505,6 +1597,9 @@ static int one_iteration(csgpu_search *s) {
                                       s->d_results, children, d_children, obj_lo, obj_hi, NULL);
   if (rc != CSGPU_OK) return rc;
   const unsigned cb = (unsigned)((children + SB - 1) / SB);
+  if (s->prefer_failing)
+    hipLaunchKernelGGL(cs_prio_update, dim3(cb), dim3(SB), 0, 0, (const csgpu_result *)s->d_results, (const csgpu_node *)s->d_nodes,
+                       (int)children, (const unsigned long long *)d_children, n, s->fail_var_known, s->d_prio);
   if (small) {
     hipLaunchKernelGGL(cs_classify_small, dim3(1), dim3(1024), 0, 0, s->d_results, s->d_dest, s->d_complete_list,
                        s->d_counters, (unsigned long long *)NULL);
@@ -1618,6 +1713,10 @@ static int enqueue_burst(csgpu_search *s, hipStream_t st) {
                                            s->d_results, bound, d_children, CS_DOM_MIN, CS_DOM_MAX,
                                            sense ? (const int32_t *)s->d_best : NULL, sense, st);
     if (rc != CSGPU_OK) return rc;
+    if (s->prefer_failing)
+      hipLaunchKernelGGL(cs_prio_update, dim3((unsigned)((bound + SB - 1) / SB)), dim3(SB), 0, st, (const csgpu_result *)s->d_results,
+                         (const csgpu_node *)s->d_nodes, (int)bound, (const unsigned long long *)d_children, n, s->fail_var_known,
+                         s->d_prio);
     hipLaunchKernelGGL(cs_classify_small, dim3(1), dim3(1024), 0, st, s->d_results, s->d_dest, s->d_complete_list,
                        s->d_counters, s->d_burst);
     hipLaunchKernelGGL(cs_scatter, dim3((unsigned)((bound + cpb - 1) / cpb)), dim3(SB), 0, st, s->d_child_states, s->d_dest,
@@ -1709,6 +1808,7 @@ extern "C" int csgpu_search_run(csgpu_search *s, int64_t max_iterations, csgpu_s
     if (s->objective == CS_OBJ_ANY && s->st.solutions > 0) break;
     int rc;
     int64_t steps = 1; /* iterations this pass of the loop made */
+    const int32_t best_before = s->st.best;
     const int restarts_on = s->restart_base > 0 && s->seed_count > 0 && s->st.solutions == 0;
     if (burst_applicable(s)) {
       int64_t budget = max_iterations - it;
@@ -1723,6 +1823,24 @@ extern "C" int csgpu_search_run(csgpu_search *s, int64_t max_iterations, csgpu_s
     } else {
       rc = one_iteration(s);
       if (rc != CSGPU_OK) return rc;
+    }
+    /* a better solution restarts a MIN / MAX search from its seeds with the new bound (update_solution +
+     * is_solution_restartable, csolve.c:216-219, 418-425) */
+    if (s->restart_on_improvement && s->seed_count > 0 && s->top > 0) {
+      const int rcf = flush_accept_results(s);
+      if (rcf != CSGPU_OK) return rcf;
+      if (s->st.best != best_before) {
+        s->st.restarts++;
+        s->top = 0;
+        const int keep_flag = s->restart_on_improvement;
+        s->restart_on_improvement = 0; /* do not record the re-seeding as new seeds */
+        const int64_t keep = s->restart_base;
+        s->restart_base = 0;
+        rc = csgpu_search_put(s, (const csgpu_val *)s->seed, s->seed_count);
+        s->restart_base = keep;
+        s->restart_on_improvement = keep_flag;
+        if (rc != CSGPU_OK) return rc;
+      }
     }
     /* check_restart (csolve.c:264-276) with Knuth's Luby sequence (csolve.c:76-83) */
     if (restarts_on && s->st.solutions == 0 &&

@@ -358,6 +358,17 @@ class Search:
     def set_restart(self, iterations: int):
         check(load_library().csgpu_search_set_restart(self._h, int(iterations)))
 
+    ORDERS = {"none": 0, "smallest-domain": 1, "largest-domain": 2, "smallest-value": 3, "largest-value": 4}
+
+    def set_strategy(self, order="smallest-domain", prefer_failing: bool = False):
+        """the reference's -o / -f (csgpu_search_set_strategy): set before the first state is put"""
+        o = self.ORDERS[order] if isinstance(order, str) else int(order)
+        check(load_library().csgpu_search_set_strategy(self._h, o, int(bool(prefer_failing))))
+
+    def set_restart_on_improvement(self, on: bool = True):
+        """MIN / MAX: restart from the seeds on every better solution (csolve.c:418-425)"""
+        check(load_library().csgpu_search_set_restart_on_improvement(self._h, int(bool(on))))
+
     def share_incumbent(self, other: "Search"):
         """keep the incumbent in `other`'s word of device memory (MIN / MAX engines of one model on one device).
         While shared, set_parents beyond the device-driven limit is refused, best_solution() answers only on the

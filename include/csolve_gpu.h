@@ -273,6 +273,18 @@ int csgpu_search_set_parents(csgpu_search *s, int64_t parents_per_iteration);
  * 264-276, default 100); every restart tries the values in a different pseudo-random rotation.
  * Default 64; 0 disables restarts. */
 int csgpu_search_set_restart(csgpu_search *s, int64_t iterations);
+/* The reference's strategy options (src/main.c:51-130, src/strategy.c:79-121), to be set before the first state is put.
+ * order: which open variable is branched on first -- 0 none, 1 smallest domain (default), 2 largest domain, 3 smallest
+ * value, 4 largest value (-o); prefer_failing != 0: among equals the variable with the highest failure count (-f):
+ * the branching variable's count goes down when an assignment holds and up when it fails, the variable whose domain
+ * emptied goes up (csolve.c:455-465, propagate.c:33-41; the reference's further bumps along its recursion stack follow
+ * its depth-first order and have no counterpart in a batch).  Ties: lowest index (the reference: heap order).
+ * Anything but the default (1, 0) takes the separate-kernel path on interval rows; with failure counts the tree of
+ * a search depends on the order in which batches finish. */
+int csgpu_search_set_strategy(csgpu_search *s, int order, int prefer_failing);
+/* MIN / MAX: a better solution restarts the search from the states it was seeded with, under the new bound
+ * (update_solution + is_solution_restartable, csolve.c:216-219, 418-425).  Off by default. */
+int csgpu_search_set_restart_on_improvement(csgpu_search *s, int on);
 /* host time csgpu_search_put / put_host have taken since the last reset (device copy + rebuilding the forbidden
  * sets of the arriving states, which travel between ranks without them) and the states they brought */
 int csgpu_search_put_cost(const csgpu_search *s, double *seconds, int64_t *states);

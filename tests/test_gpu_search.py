@@ -216,6 +216,63 @@ def test_command_line_front_prints_in_the_reference_format():
     assert "INFEASIBLE PROBLEM" in p.stdout or "NO SOLUTION FOUND" in p.stdout
 
 
+@pytest.mark.parametrize("order", ["none", "smallest-domain", "largest-domain", "smallest-value", "largest-value"])
+@pytest.mark.parametrize("prefer", [False, True])
+def test_the_references_variable_orders_and_failure_counts(order, prefer):
+    """-o / -f (strategy.c:79-121) in the engine: whatever the branching rule, ALL finds every solution, ANY a valid one,
+    MIN the optimum; with the default rule set explicitly the tree is the default engine's"""
+    from csolve_amd import problems
+    from csolve_amd.solver import Search, solve_root
+    model = solve_root(problems.queens(8, "ALL"))
+    s = Search(model, 1 << 16, 1 << 12)
+    s.set_strategy(order, prefer)
+    s.put(model.root_state())
+    st = s.run()
+    assert st["done"] == 1 and st["solutions"] == 92
+    if order == "smallest-domain" and not prefer:
+        ref = Search(model, 1 << 16, 1 << 12)
+        ref.put(model.root_state())
+        rst = ref.run()
+        assert (st["nodes"], st["cuts"], st["props"]) == (rst["nodes"], rst["cuts"], rst["props"])
+    model = solve_root(problems.queens(24))
+    s = Search(model, 1 << 18, 1 << 14)
+    s.set_strategy(order, prefer)
+    s.put(model.root_state())
+    st = s.run(200000)
+    assert st["done"] == 1 and st["solutions"] >= 1
+    row = s.solutions(1)[0]
+    assert len(set(row)) == 24 and len(set(row + np.arange(24))) == 24 and len(set(row - np.arange(24))) == 24
+    model = solve_root(open(golden("problems", "schedule6_s1.txt")).read())
+    s = Search(model, 1 << 18, 1 << 14)
+    s.set_strategy(order, prefer)
+    s.set_restart_on_improvement(True)
+    s.put(model.root_state())
+    st = s.run()
+    assert st["done"] == 1 and st["best"] == 22 and st["restarts"] >= 1
+
+
+def test_command_line_flags_of_the_reference(tmp_path):
+    """csolve_gpu -o / -f / -r / -t / -c / -j (main.c:51-130): the same solutions and optimum under every flag set, a
+    time limit ends an ALL run early"""
+    import os
+    import subprocess
+    from conftest import ROOT
+    from csolve_amd import problems
+    exe = os.path.join(ROOT, "csolve_amd", "csolve_gpu")
+    for flags in (["-o", "none", "-f", "true"], ["-o", "largest-domain", "-f", "false", "-c", "true", "-j", "4"],
+                  ["-r", "0"], ["-o", "smallest-value", "-r", "100", "-t", "60"]):
+        p = subprocess.run([exe] + flags + [golden("problems", "queens8_all.txt")], capture_output=True, text=True, timeout=120)
+        assert p.returncode == 0 and p.stdout.count("SOLUTION: ") == 92, (flags, p.stderr)
+        p = subprocess.run([exe] + flags + [golden("problems", "ref_schedule.txt")], capture_output=True, text=True, timeout=120)
+        assert p.stdout.count("SOLUTION: ") == 1 and "BEST: 11" in p.stdout, (flags, p.stdout[-300:])
+    big = tmp_path / "q40all.txt"
+    big.write_text(problems.queens(40, "ALL"))
+    p = subprocess.run([exe, "-t", "1", str(big)], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and "CALLS:" in p.stdout
+    p = subprocess.run([exe, "-o", "sideways", golden("problems", "queens8_all.txt")], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 1 and "error: invalid order" in p.stderr
+
+
 def test_reset_runs_the_same_search_again():
     from csolve_amd import problems
     from csolve_amd.solver import Search, solve_root

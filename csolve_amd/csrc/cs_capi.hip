@@ -93,6 +93,7 @@ struct csgpu_model {
   cs_val *d_one_in, *d_one_out;  /* device views of the four parts */
   cs_node_in *d_one_node;
   cs_node_out *d_one_res;
+  int engines; /* csgpu_search objects built on this model (they hold pointers into its device tables) */
   /* the resident single-node server (cs_shave_server): its mailbox in coherent host memory, its stream, the last
    * request number; srv_off: not used for this model (it does not qualify, or CSGPU_SERVER=0) */
   unsigned char *h_box;   /* [cs_mailbox_head | state_in | state_out | trace] */
@@ -466,7 +467,12 @@ extern "C" int csgpu_model_add_conflict(csgpu_model *m, int32_t count, const int
   cs_model *h = m->host;
   if (h->root < 0) return set_err(CSGPU_E_STATE, "model has no root");
   if (count + 1 > CS_MAX_TREE_NODES) return set_err(CSGPU_E_LIMIT, "a conflict of %d elements, device limit is %d", count, CS_MAX_TREE_NODES - 1);
+  /* a finalized model is finalized again below, which frees every device table: a search engine built on the model
+   * (its captured hipGraphs, its kernels' arguments) would go on using the freed pointers */
+  if (m->finalized && m->engines > 0)
+    return set_err(CSGPU_E_STATE, "%d search engine(s) hold the model's device tables: free them before adding a clause", m->engines);
   int32_t *terms = (int32_t *)malloc((size_t)count * sizeof(int32_t));
+  if (terms == NULL) return set_err(CSGPU_E_LIMIT, "out of memory");
   for (int32_t i = 0; i < count; i++) {
     if (vars[i] < 0 || vars[i] >= h->n_vars) {
       free(terms);
@@ -955,6 +961,10 @@ extern "C" int csgpu_model_qualifies(const csgpu_model *m, int which) {
   case 5: return m->dense_waves != 0 && packed_nodes_per_wave(m->fb_words, m->host->n_vars, m->img->dense_width) != 0;
   default: return 0;
   }
+}
+
+extern "C" void csgpu_internal_engine_ref(const csgpu_model *m, int delta) {
+  if (m != NULL) const_cast<csgpu_model *>(m)->engines += delta;
 }
 
 extern "C" const int32_t *csgpu_internal_root_lo(const csgpu_model *m) {

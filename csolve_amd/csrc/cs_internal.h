@@ -32,6 +32,9 @@ int csgpu_internal_propagate_objdev(const csgpu_model *m, const csgpu_val *d_sta
 /* root lower bounds of the variables in device memory (NULL unless the model qualifies for the forbidden-set
  * kernels): bit k of a set word = value root_lo + k */
 const int32_t *csgpu_internal_root_lo(const csgpu_model *m);
+/* a search engine is built on / freed from the model: while any exists csgpu_model_add_conflict on the finalized
+ * model is refused (it would free the device tables the engine's kernels and graphs point into) */
+void csgpu_internal_engine_ref(const csgpu_model *m, int delta);
 /* csgpu_eval_batch over the rows d_list[0 .. *d_count) of d_states, *d_count <= bound */
 int csgpu_internal_eval_list(const csgpu_model *m, const csgpu_val *d_states, const int32_t *d_list,
                              const uint64_t *d_count, int64_t bound, int32_t *d_truth, void *stream);

@@ -126,6 +126,7 @@ struct csgpu_search {
   cs_holes holes;      /* values a parent's own set forbids are cut without a launch (one set word per variable) */
   /* fused levels (cs_step.hip.h): ALL on models with a step kernel -- the pool holds interval rows only, a frontier is
    * one launch (branch + fixpoints + store) plus cs_collect */
+  int counted; /* this engine is in its model's engine count */
   int fused;
   int64_t stage_rows;           /* rows of d_child_states, the staging buffer of the survivors */
   uint32_t *d_fill, *d_ticket;
@@ -988,6 +989,7 @@ extern "C" void csgpu_search_free(csgpu_search *s) {
     if (--l->borrowers == 0 && l->free_pending) csgpu_search_free(l);
   }
   (void)hipSetDevice(s->device);
+  if (s->counted) csgpu_internal_engine_ref(s->m, -1);
   (void)hipFree(s->pool_forb); (void)hipFree(s->d_child_forb); (void)hipFree(s->d_rebuild_nodes);
   (void)hipFree(s->pool); (void)hipFree(s->d_choice); (void)hipFree(s->d_child_off); (void)hipFree(s->d_block_sum); (void)hipFree(s->d_block_skip);
   (void)hipFree(s->d_nodes); (void)hipFree(s->d_child_states); (void)hipFree(s->d_complete_states);
@@ -1016,6 +1018,8 @@ extern "C" int csgpu_search_create(const csgpu_model *m, int64_t pool_capacity, 
   s->m = m;
   s->n = n;
   if (hipGetDevice(&s->device) != hipSuccess) { free(s); return fail(CSGPU_E_HIP, "hipGetDevice"); }
+  csgpu_internal_engine_ref(m, 1);
+  s->counted = 1;
   s->objective = csgpu_model_objective(m);
   s->obj_var = csgpu_model_objective_var(m);
   /* widest root interval bounds the branching factor (domains only shrink below the root) */

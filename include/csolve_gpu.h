@@ -117,7 +117,9 @@ int csgpu_model_normalize(csgpu_model *m);
  * (propagate.c:395-471: when every element but one has its conflict value, that value is shaved off the bound of
  * the remaining variable it sits on).  The clause becomes the last top-level clause and the last entry of its
  * variables' clause lists.  May be called before or after csgpu_model_finalize; afterwards the device tables are
- * rebuilt (the call costs O(model)).  At most 255 elements (CSGPU_E_LIMIT). */
+ * rebuilt (the call costs O(model)) -- which frees the old ones: while a csgpu_search built on the model exists (its
+ * kernels' arguments and captured graphs point into them) the call is refused with CSGPU_E_STATE; free the engines
+ * first.  At most 255 elements (CSGPU_E_LIMIT). */
 int csgpu_model_add_conflict(csgpu_model *m, int32_t count, const int32_t *vars, const int32_t *values);
 
 /* eval_<op> on the current root domains, host buffers, no finalize needed (variables may

@@ -167,4 +167,32 @@ CS_HD static inline int32_t cs_step_val(cs_val bounds, uint32_t iter, uint32_t s
   return ((iter ^ seed) & 1u) ? (int32_t)((uint32_t)bounds.hi - (iter >> 1)) : (int32_t)((uint32_t)bounds.lo + (iter >> 1));
 }
 
+/* The branching rule's key (strategy_var_cmp, reference src/strategy.c:79-121): the variable with the SMALLEST key is
+ * branched on first -- what the reference keeps at the top of its heap.  order: 0 none, 1 smallest domain, 2 largest
+ * domain, 3 smallest value, 4 largest value; then, with prefer_failing, the higher failure count; the caller breaks
+ * remaining ties by index.  Domain sizes saturate like the reference's add() does (arith.c:38-51): an interval with a
+ * bound at DOMAIN_MIN / DOMAIN_MAX has the largest size there is. */
+CS_HD static inline uint32_t cs_order_key(int order, cs_val d) {
+  const int unbounded = d.lo == CS_DOM_MIN || d.hi == CS_DOM_MAX || d.lo == CS_DOM_MAX || d.hi == CS_DOM_MIN;
+  const int64_t w = (int64_t)d.hi - (int64_t)d.lo;
+  const uint32_t size = unbounded || w > 0x7ffffffell ? 0x7fffffffu : (w < 0 ? 0u : (uint32_t)w); /* width - 1, saturated */
+  switch (order) {
+  case 0: return 0u;
+  case 1: return size;
+  case 2: return 0x7fffffffu - size;
+  case 3: return (uint32_t)d.lo ^ 0x80000000u;               /* lower bound, as an unsigned rank */
+  case 4: return 0xffffffffu - ((uint32_t)d.hi ^ 0x80000000u); /* higher upper bound first */
+  default: return size;
+  }
+}
+CS_HD static inline uint64_t cs_branch_key_of(int order, int prefer_failing, cs_val d, int64_t prio, int index) {
+  uint32_t pk = 0u;
+  if (prefer_failing) {
+    int64_t p = prio + 32768;
+    p = p < 0 ? 0 : (p > 65535 ? 65535 : p);
+    pk = 65535u - (uint32_t)p;
+  }
+  return ((uint64_t)cs_order_key(order, d) << 32) | ((uint64_t)pk << 16) | (uint64_t)((uint32_t)index & 0xffffu);
+}
+
 #endif /* CS_ARITH_H */

@@ -158,6 +158,9 @@ extern "C" void csgpu_luby_next(uint64_t *threshold, uint64_t *counter) {
 extern "C" int csgpu_step_check(csgpu_val bounds, uint32_t iter) {
   return cs_step_check(cs_interval(bounds.lo, bounds.hi), iter);
 }
+extern "C" uint64_t csgpu_branch_key(int order, int prefer_failing, csgpu_val value, int64_t prio, int32_t index) {
+  return cs_branch_key_of(order, prefer_failing, cs_interval(value.lo, value.hi), prio, index);
+}
 extern "C" int32_t csgpu_step_val(csgpu_val bounds, uint32_t iter, uint32_t seed) {
   return cs_step_val(cs_interval(bounds.lo, bounds.hi), iter, seed);
 }

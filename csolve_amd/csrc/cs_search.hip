@@ -40,25 +40,10 @@ struct cs_holes {
   const int *prio;
 };
 
-/* the part of the branching key that the state decides: smaller comes first */
-__device__ __forceinline__ unsigned cs_order_key(int order, cs_val d) {
-  switch (order) {
-  case 0: return 0u;
-  case 2: return 0xffffffffu - (unsigned)((long long)d.hi - (long long)d.lo);
-  case 3: return (unsigned)d.lo ^ 0x80000000u;
-  case 4: return 0x7fffffffu - (unsigned)d.hi + 0x80000000u; /* INT_MAX - hi, as an unsigned rank */
-  default: return (unsigned)((long long)d.hi - (long long)d.lo); /* width - 1 */
-  }
-}
-/* ... and the whole key: state part, then failure count (higher first), then index */
+/* the whole key: state part, then failure count (higher first), then index (cs_arith.h: the same function is
+ * exported as csgpu_branch_key and pinned by the reference's VarCmp vectors) */
 __device__ __forceinline__ unsigned long long cs_branch_key(const cs_holes &H, cs_val d, int v) {
-  unsigned pk = 0u;
-  if (H.prio != nullptr) {
-    int p = H.prio[v] + 32768;
-    p = p < 0 ? 0 : (p > 65535 ? 65535 : p);
-    pk = 65535u - (unsigned)p;
-  }
-  return ((unsigned long long)cs_order_key(H.order, d) << 32) | ((unsigned long long)pk << 16) | (unsigned long long)(unsigned)(v & 0xffff);
+  return cs_branch_key_of(H.order, H.prio != nullptr, d, H.prio != nullptr ? (long long)H.prio[v] : 0ll, v);
 }
 
 /* what the branching step decides for a parent and the emitting step needs (32 bytes per parent) */

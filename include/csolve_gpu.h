@@ -306,6 +306,11 @@ void csgpu_luby_next(uint64_t *threshold, uint64_t *counter);
 /* step_check / step_val (csolve.c:323-338): is iteration `iter` over `bounds` valid, and the value it tries */
 int csgpu_step_check(csgpu_val bounds, uint32_t iter);
 int32_t csgpu_step_val(csgpu_val bounds, uint32_t iter, uint32_t seed);
+/* strategy_var_cmp (strategy.c:79-121) as a key: the engine branches on the open variable with the SMALLEST key (what
+ * the reference's heap has on top); order 0 none / 1 smallest domain / 2 largest domain / 3 smallest value / 4 largest
+ * value, then (prefer_failing) the higher failure count, then the lower index.  sign(strategy_var_cmp(a, b)) =
+ * sign(key(b) - key(a)) with the index bits masked (test/test_strategy.c VarCmp.*). */
+uint64_t csgpu_branch_key(int order, int prefer_failing, csgpu_val value, int64_t prio, int32_t index);
 
 /* merge an incumbent found elsewhere (objective_best of the shared page, objective.c:89-93) */
 int csgpu_search_set_best(csgpu_search *s, int32_t best);

@@ -339,3 +339,26 @@ def test_front_end_weights_as_the_reference_grammar_prescribes():
         m = OModel.parse(case["text"], weights_on=True)
         got = dict(zip(m.names(), [m.view.prio[i] for i in range(m.n_vars)]))
         assert got == case["prio"], (case["text"], got)
+
+
+def test_the_engines_branching_key_orders_variables_like_strategy_var_cmp():
+    """csgpu_branch_key (cs_arith.h: what cs_branch and the burst kernels minimise over the open variables) against the
+    70 comparisons of test/test_strategy.c VarCmp.*: sign(strategy_var_cmp(a, b)) = sign(key(b) - key(a)) with the
+    index bits masked -- the variable the reference's heap would pop is the one with the smallest key"""
+    import ctypes as C
+    import json
+    from csolve_amd import _lib
+    L = _lib.load_library()
+    L.csgpu_branch_key.argtypes = [C.c_int, C.c_int, _lib.Val, C.c_int64, C.c_int32]
+    L.csgpu_branch_key.restype = C.c_uint64
+    kinds = {"none": 0, "smallest-domain": 1, "largest-domain": 2, "smallest-value": 3, "largest-value": 4}
+    from conftest import golden
+    cases = json.load(open(golden("ref_unit_strategy.json")))["cmp"]
+    assert len(cases) == 70
+    for c in cases:
+        ka = L.csgpu_branch_key(kinds[c["order"]], int(c["prefer_failing"]), _lib.Val(*c["a"]["val"]), c["a"]["prio"], 0) >> 16
+        kb = L.csgpu_branch_key(kinds[c["order"]], int(c["prefer_failing"]), _lib.Val(*c["b"]["val"]), c["b"]["prio"], 0) >> 16
+        sign = (kb > ka) - (kb < ka)
+        assert sign == c["sign"], (c, ka, kb)
+    # ties go to the lower index
+    assert L.csgpu_branch_key(1, 0, _lib.Val(1, 5), 0, 3) < L.csgpu_branch_key(1, 0, _lib.Val(1, 5), 0, 4)

@@ -127,6 +127,7 @@ def load_library():
     L.csgpu_propagate_one_causes.argtypes = [vp, vp, Node, vp, C.POINTER(Result), vp, i32, C.POINTER(i32)]
     L.csgpu_propagate_values.argtypes = [vp, vp, i32, vp, i32, vp, vp]
     L.csgpu_model_root_propagate_limit.argtypes = [vp, i64, C.POINTER(i32), C.POINTER(i32)]
+    L.csgpu_propagate_one_chain.argtypes = [vp, vp, Node, C.POINTER(i32), C.POINTER(i32), vp, i32, C.POINTER(i32)]
     L.csgpu_search_set_strategy.argtypes = [vp, C.c_int, C.c_int]
     L.csgpu_search_set_restart_on_improvement.argtypes = [vp, C.c_int]
     _lib = L

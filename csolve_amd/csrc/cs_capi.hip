@@ -16,6 +16,7 @@
 #include "cs_kernels.hip.h"
 #include "cs_shave.hip.h"
 #include "cs_step.hip.h"
+#include "cs_chain.hip.h"
 #include "cs_internal.h"
 
 static thread_local char g_err[512] = "";
@@ -94,6 +95,13 @@ struct csgpu_model {
   cs_node_in *d_one_node;
   cs_node_out *d_one_res;
   int engines; /* csgpu_search objects built on this model (they hold pointers into its device tables) */
+  /* csgpu_propagate_one_chain (cs_chain.hip.h): clause shapes and lists on the device, the frame stack, the mapped
+   * host buffers; chain_state: 0 not built yet, 1 ready, -1 the model does not qualify */
+  int chain_state;
+  cs_chain_clause *d_chain_cl;
+  int *d_chain_off, *d_chain_list;
+  cs_chain_frame *d_chain_frames;
+  int *h_chain_out; /* mapped: [4] out, then the bumps */
   /* the resident single-node server (cs_shave_server): its mailbox in coherent host memory, its stream, the last
    * request number; srv_off: not used for this model (it does not qualify, or CSGPU_SERVER=0) */
   unsigned char *h_box;   /* [cs_mailbox_head | state_in | state_out | trace] */
@@ -236,6 +244,10 @@ static void quiesce_servers(void) {
 }
 
 static void free_device(csgpu_model *m) {
+  (void)hipFree(m->d_chain_cl); (void)hipFree(m->d_chain_off); (void)hipFree(m->d_chain_list); (void)hipFree(m->d_chain_frames);
+  if (m->h_chain_out != NULL) (void)hipHostFree(m->h_chain_out);
+  m->d_chain_cl = NULL; m->d_chain_off = NULL; m->d_chain_list = NULL; m->d_chain_frames = NULL; m->h_chain_out = NULL;
+  m->chain_state = 0;
   quiesce_servers(); /* before anything is freed: this model's resident wave reads the tables, and hipFree waits for all of them */
   for (int i = 0; i < 16; i++)
     if (g_srv_models[i] == m) g_srv_models[i] = NULL;
@@ -1980,6 +1992,84 @@ extern "C" int csgpu_propagate_one_causes(const csgpu_model *cm, const csgpu_val
   memcpy(trace, m->h_trace, (size_t)kept * 16);
   m->srv_seconds[0] += tl1 - tl0; m->srv_seconds[1] += tl2 - tl1; m->srv_seconds[2] += tl3 - tl2; m->srv_seconds[3] += srv_now() - tl3;
   m->srv_calls++;
+  return CSGPU_OK;
+}
+
+/* ---- the reference's own failure chain of one node (cs_chain.hip.h) ---- */
+#define CS_CHAIN_FRAMES (1 << 16)
+#define CS_CHAIN_BUMPS 4096
+
+/* operand of NOT(EQ(l, r)): a variable, or `variable + constant` with the constant on the right */
+static int chain_operand(const cs_model *h, int32_t node, int *x, int *c) {
+  const cs_node *nd = &h->nodes[node];
+  if (nd->op == CS_OP_VAR) { *x = nd->a; *c = 0; return 1; }
+  if (nd->op == CS_OP_ADD) {
+    const cs_node *l = &h->nodes[nd->a], *r = &h->nodes[nd->b];
+    if (l->op == CS_OP_VAR && r->op == CS_OP_CONST && r->a == r->b) { *x = l->a | CS_CHAIN_ADD; *c = r->a; return 1; }
+  }
+  return 0;
+}
+
+static int chain_build(csgpu_model *m) {
+  if (m->chain_state != 0) return m->chain_state;
+  const cs_model *h = m->host;
+  m->chain_state = -1;
+  if (!m->finalized || h->n_clauses < 1 || h->n_clauses > 60000 || h->n_vars < 1 || h->list_off == NULL) return -1;
+  if ((size_t)h->n_vars * sizeof(cs_val) + (size_t)h->n_clauses * 2 + 64 > 160u * 1024u) return -1;
+  cs_chain_clause *cl = (cs_chain_clause *)malloc((size_t)h->n_clauses * sizeof *cl);
+  if (cl == NULL) return -1;
+  for (int32_t c = 0; c < h->n_clauses; c++) {
+    const cs_node *top = &h->nodes[h->clause_node[c]];
+    int ok = top->op == CS_OP_NOT && h->nodes[top->a].op == CS_OP_EQ;
+    if (ok) {
+      const cs_node *eq = &h->nodes[top->a];
+      ok = chain_operand(h, eq->a, &cl[c].lx, &cl[c].lc) && chain_operand(h, eq->b, &cl[c].rx, &cl[c].rc);
+    }
+    if (!ok) { free(cl); return -1; } /* another clause shape: the walk of cs_chain.hip.h does not cover it */
+  }
+  int rc = upload(cl, (size_t)h->n_clauses * sizeof *cl, (int **)&m->d_chain_cl);
+  free(cl);
+  if (rc == CSGPU_OK) rc = upload(h->list_off, ((size_t)h->n_vars + 1) * sizeof(int32_t), &m->d_chain_off);
+  if (rc == CSGPU_OK) rc = upload(h->list, (size_t)(h->list_off[h->n_vars] ? h->list_off[h->n_vars] : 1) * sizeof(int32_t), &m->d_chain_list);
+  if (rc != CSGPU_OK) return -1;
+  if (hipMalloc((void **)&m->d_chain_frames, (size_t)CS_CHAIN_FRAMES * sizeof(cs_chain_frame)) != hipSuccess ||
+      hipHostMalloc((void **)&m->h_chain_out, (4 + CS_CHAIN_BUMPS) * sizeof(int), hipHostMallocMapped) != hipSuccess ||
+      hipFuncSetAttribute((const void *)cs_ne_chain, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+    (void)hipGetLastError();
+    return -1;
+  }
+  m->chain_state = 1;
+  return 1;
+}
+
+extern "C" int csgpu_propagate_one_chain(const csgpu_model *cm, const csgpu_val *state, csgpu_node node, int32_t *status,
+                                         int32_t *props_out, int32_t *bumps, int32_t cap, int32_t *count) {
+  csgpu_model *m = const_cast<csgpu_model *>(cm);
+  if (m == NULL || state == NULL || status == NULL || props_out == NULL || bumps == NULL || count == NULL || cap < 0)
+    return set_err(CSGPU_E_ARG, "bad argument");
+  if (!m->finalized) return set_err(CSGPU_E_STATE, "model is not finalized");
+  if (node.var < 0 || node.var >= m->host->n_vars) return set_err(CSGPU_E_ARG, "no such variable");
+  if (chain_build(m) != 1)
+    return set_err(CSGPU_E_LIMIT, "the model is not a network of NOT(EQ(x [+ c], y [+ d])) clauses: no reference-order walk");
+  const size_t nbytes = (size_t)m->host->n_vars * sizeof(cs_val);
+  memcpy(m->h_one, state, nbytes); /* the mapped staging area of the single-node calls */
+  void *dev = NULL;
+  HIP_TRY(hipHostGetDevicePointer(&dev, m->h_chain_out, 0));
+  int *d_out = (int *)dev, *d_bumps = (int *)dev + 4;
+  cs_node_in nd;
+  nd.var = node.var; nd.lo = node.lo; nd.hi = node.hi; nd.parent = 0;
+  const size_t lds = ((nbytes + 15) & ~(size_t)15) + (((size_t)m->host->n_clauses * 2 + 15) & ~(size_t)15);
+  hipLaunchKernelGGL(cs_ne_chain, dim3(1), dim3(64), lds, (hipStream_t)NULL, m->host->n_vars, m->host->n_clauses,
+                     (const cs_chain_clause *)m->d_chain_cl, (const int *)m->d_chain_off, (const int *)m->d_chain_list,
+                     (const cs_val *)m->d_one_in, nd, m->d_chain_frames, (int)CS_CHAIN_FRAMES, d_out, d_bumps, (int)CS_CHAIN_BUMPS);
+  HIP_TRY(hipGetLastError());
+  { const int rcw = wait_null_stream(); if (rcw != CSGPU_OK) return rcw; }
+  if (m->h_chain_out[3] != 0) return set_err(CSGPU_E_LIMIT, "the reference-order walk overflowed its frame stack or its bump list");
+  *status = m->h_chain_out[0];
+  *props_out = m->h_chain_out[1];
+  const int made = m->h_chain_out[2];
+  *count = made;
+  memcpy(bumps, m->h_chain_out + 4, (size_t)(made < cap ? made : cap) * sizeof(int32_t));
   return CSGPU_OK;
 }
 

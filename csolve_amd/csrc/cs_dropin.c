@@ -564,11 +564,27 @@ static int learning(void) {
  * be read off it: from the failing variable to the other variable of the clause that failed it, to the clause that
  * had narrowed THAT one, and so on back to the assignment.  It is a causal chain of the same kind, not necessarily
  * the one the depth-first order would have walked.  CSOLVE_DROPIN_CHAIN=0 switches it off. */
+/* CSOLVE_DROPIN_CHAIN=reference: the reference's OWN chain.  A failing node is walked once more in the reference's
+ * depth-first order by one wavefront (csgpu_propagate_one_chain, cs_chain.hip.h), which names exactly the variables
+ * propagate_term_confl / propagate_term_recurse would bump, in their order, and counts the narrowings made before the
+ * failure: the driver's search is then call for call the all-CPU reference's (CALLS, CUTS, PROPS, RESTARTS), at tens
+ * of microseconds per failing node instead of a few. */
+static int reference_chain(void) {
+  static int on = -1;
+  if (on < 0) {
+    const char *e = getenv("CSOLVE_DROPIN_CHAIN");
+    on = e != NULL && strcmp(e, "reference") == 0;
+  }
+  return on && strategy_prefer_failing();
+}
+static uint64_t g_reference_walks;
+uint64_t csolve_dropin_reference_walks(void) { return g_reference_walks; }
+
 static int chain_mode(void) {
   static int on = -1;
   if (on < 0) {
     const char *e = getenv("CSOLVE_DROPIN_CHAIN");
-    on = e == NULL || atoi(e) != 0;
+    on = e == NULL || strcmp(e, "reference") == 0 || atoi(e) != 0;
   }
   return on && strategy_prefer_failing();
 }
@@ -801,6 +817,28 @@ static prop_result_t propagate_clauses_timed(const struct clause_list_t *clauses
     int32_t count = 0;
     const int rc = csgpu_propagate_one_causes(g_model, g_state, node, g_out, &res, g_trail, CS_TRAIL_CAP, &count);
     if (rc == CSGPU_OK) {
+      static int no_walk; /* the model has clauses the reference-order walk does not cover: the causal chain instead */
+      if (res.status < 0 && reference_chain() && !no_walk) {
+        int32_t st = 0, pr = 0, nb = 0;
+        const int rcw = csgpu_propagate_one_chain(g_model, g_state, node, &st, &pr, g_trail, CS_TRAIL_CAP, &nb);
+        if (rcw == CSGPU_OK && st < 0) {
+          g_seconds[1] += now_s() - td;
+          g_reference_walks++;
+          props += (uint64_t)pr;
+          for (int32_t i = 0; i < nb && i < CS_TRAIL_CAP; i++) {
+            const int32_t b = g_trail[i];
+            if (b < 0 || (size_t)b >= g_size) continue;
+            g_env[b].prio++;
+            strategy_var_order_update(&g_env[b]);
+            g_chain_bumps++;
+          }
+          TRACE("[dropin]   -> failed; reference-order walk: %d narrowings, %d variables bumped\n", pr, nb);
+          g_last_res = res;
+          return PROP_ERROR;
+        }
+        if (rcw != CSGPU_OK && rcw != CSGPU_E_LIMIT) fatal_gpu("propagate_clauses");
+        no_walk = 1;
+      }
       g_seconds[1] += now_s() - td;
       TRACE("[dropin]   -> status %d props %d, %d cause records\n", res.status, res.props, count);
       g_last_res = res;

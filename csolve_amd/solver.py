@@ -275,6 +275,16 @@ class Model:
             raise OverflowError(f"{cnt.value} trace records, {min(cap, 2048)} kept")
         return res.status, res.props, (out if res.status >= 0 else None), trace[: cnt.value].copy()
 
+    def propagate_one_chain(self, state: np.ndarray, var: int, lo: int, hi: int, cap: int = 4096):
+        """The reference's own failure chain of one node (csgpu_propagate_one_chain).
+        -> (status -1 / 0, props, bumped variables in the reference's order)"""
+        state = np.ascontiguousarray(state, dtype=np.int32)
+        st, props, cnt = C.c_int32(), C.c_int32(), C.c_int32()
+        bumps = np.empty(cap, dtype=np.int32)
+        check(load_library().csgpu_propagate_one_chain(self._h, state.ctypes.data, Node(var, lo, hi, 0), C.byref(st),
+                                                        C.byref(props), bumps.ctypes.data, cap, C.byref(cnt)))
+        return st.value, props.value, bumps[: min(cap, cnt.value)].copy()
+
     def propagate_one_traced(self, state: np.ndarray, var: int, lo: int, hi: int, cap: int = 4096):
         """One node with its trail (csgpu_propagate_one_traced).
         -> (status, props, fixpoint or None, trace [k, 4] = {variable, 0 lo / 1 hi / 2 failure, new bound, clause})"""

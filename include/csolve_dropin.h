@@ -122,6 +122,8 @@ void csolve_dropin_learning_counters(uint64_t out[2]);
 void csolve_dropin_seconds(double out[3]);
 /* seconds spent inside the eval entry points (update_solution evaluates the root once per complete assignment) */
 double csolve_dropin_eval_seconds(void);
+/* failing nodes walked in the reference's own order (CSOLVE_DROPIN_CHAIN=reference) */
+uint64_t csolve_dropin_reference_walks(void);
 /* device time of the propagate_clauses calls so far, in microseconds: { first call, median, 90th percentile, maximum } */
 void csolve_dropin_call_times(double out[4]);
 

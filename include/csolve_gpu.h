@@ -369,6 +369,16 @@ int csgpu_propagate_one_traced(const csgpu_model *m, const csgpu_val *state, csg
  * variables on the way from the assignment to a failure (propagate_term_recurse, propagate.c:44-54). */
 int csgpu_propagate_one_causes(const csgpu_model *m, const csgpu_val *state, csgpu_node node, csgpu_val *state_out,
                                csgpu_result *result, int32_t *trace, int32_t cap, int32_t *count);
+/* The reference's OWN failure chain of one node: which variables its depth-first propagation bumps when the node fails
+ * -- the variable whose domain emptied (propagate_term_confl, propagate.c:33-41; none when the failure is found at the
+ * constant of an `x + c` operand) and then every variable on its recursion stack, innermost first
+ * (propagate_term_recurse, propagate.c:44-54) -- and how many narrowings it made before (its PROPS of the call).  One
+ * wavefront walks the reference's recursion (cs_chain.hip.h); for models whose clauses are all NOT(EQ(l, r)) with l, r a
+ * variable or `variable + constant` (CSGPU_E_LIMIT otherwise).  *status = -1 (failed) or 0; bumps[0 .. min(cap, *count))
+ * in the reference's order.  Tens of microseconds per node: the drop-in uses it for failing nodes only, and only when
+ * asked for the reference's exact trace (CSOLVE_DROPIN_CHAIN=reference). */
+int csgpu_propagate_one_chain(const csgpu_model *m, const csgpu_val *state, csgpu_node node, int32_t *status,
+                              int32_t *props, int32_t *bumps, int32_t cap, int32_t *count);
 /* THE RESIDENT SERVER behind the two entries above.  One propagate_clauses of the reference's driver (csolve.c:247-261)
  * is one node; as a kernel launch it costs launch submit + dispatch + completion signal + the host's wait, 14 of the
  * 19 us of a call.  For the models of kernel 7 (pure != networks of at most 256 variables) csgpu_propagate_one and

@@ -77,7 +77,20 @@ struct cso {
   int32_t *order;    /* env_t.order, -1 = not in heap */
   int32_t heap_n;
   int prefer_failing, order_kind;
+  /* test hook: the variables whose priority a failing call bumped, in order (propagate.c:33-54) */
+  int32_t bump_log[4096];
+  int32_t bump_n;
 };
+
+static void note_bump(cso *o, int32_t var) {
+  if (o->bump_n < 4096) o->bump_log[o->bump_n] = var;
+  o->bump_n++;
+}
+int32_t cso_test_bumps(const cso *o, int32_t *out, int32_t cap) {
+  const int32_t k = o->bump_n < 4096 ? o->bump_n : 4096;
+  for (int32_t i = 0; i < k && i < cap; i++) out[i] = o->bump_log[i];
+  return o->bump_n;
+}
 
 cso *cso_new(const cs_model *m) {
   cso *o = (cso *)calloc(1, sizeof *o);
@@ -357,6 +370,7 @@ static int32_t prop_var(cso *o, int32_t var, cs_val val, int32_t clause) {
   if (t.lo > val.hi || t.hi < val.lo) {
     if (has_env) {
       o->prio[var]++;
+      note_bump(o, var);
       heap_update(o, var);
     }
     return CSO_ERROR;
@@ -373,6 +387,7 @@ static int32_t prop_var(cso *o, int32_t var, cs_val val, int32_t clause) {
   int32_t p = cso_propagate_clauses(o, var);
   if (p == CSO_ERROR) {
     o->prio[var]++;
+    note_bump(o, var);
     heap_update(o, var);
     return CSO_ERROR;
   }
@@ -605,6 +620,7 @@ int64_t cso_instance(cso *o, const cs_val *dom_in, int32_t var, cs_val val, cs_v
   memcpy(o->dom, dom_in, (size_t)m->n_vars * sizeof(cs_val));
   o->trail_n = 0;
   o->props = 0;
+  o->bump_n = 0;
   int32_t r;
   if (var >= 0) {
     o->root_phase = 0;

@@ -86,6 +86,9 @@ void cso_log_clear(cso *o);
  * Returns CSO_ERROR or the reference's PROPS for this node; dom_out (may alias
  * dom_in) receives the domains (meaningful only on success). */
 int64_t cso_instance(cso *o, const cs_val *dom_in, int32_t var, cs_val val, cs_val *dom_out);
+/* test hook: the variables whose priority the last cso_instance bumped, in the reference's order (the variable whose
+ * domain emptied, then the recursion stack innermost first: propagate.c:33-54); returns how many there were */
+int32_t cso_test_bumps(const cso *o, int32_t *out, int32_t cap);
 
 /* cso_instance over a batch with single-value assignments.  states_in holds the parent
  * states ([*][n_vars]); nodes[i] = {var, lo, hi, parent_row}; status[i] = CSO_ERROR or PROPS;

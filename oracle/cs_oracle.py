@@ -106,6 +106,8 @@ def lib():
         L.cso_log_len.argtypes = [vp]
         L.cso_log_get.argtypes = [vp, sz, C.POINTER(i32), C.POINTER(Val)]
         L.cso_log_clear.argtypes = [vp]
+        L.cso_test_bumps.restype = i32
+        L.cso_test_bumps.argtypes = [vp, vp, i32]
         L.cso_instance.restype = i64
         L.cso_instance.argtypes = [vp, vp, i32, Val, vp]
         L.cso_instances.restype = u64
@@ -324,6 +326,12 @@ class Oracle:
         out = np.empty_like(dom_in)
         st = lib().cso_instance(self.ptr, dom_in.ctypes.data, var, Val(lo, hi), out.ctypes.data)
         return int(st), out
+
+    def bumps(self, cap: int = 4096) -> np.ndarray:
+        """variables whose priority the last instance() bumped, in the reference's order (failing calls only)"""
+        out = np.empty(cap, dtype=np.int32)
+        k = lib().cso_test_bumps(self.ptr, out.ctypes.data, cap)
+        return out[: min(k, cap)].copy()
 
     def instances(self, dom_in: np.ndarray, var: np.ndarray, val: np.ndarray):
         """Batch of single-value assignments: dom_in [B,n,2], var [B], val [B]."""

@@ -148,6 +148,35 @@ def test_reference_driver_with_conflict_learning_on_gpu_propagator(n, m, seed, t
 
 
 @pytest.mark.skipif(not (os.path.exists(BIN) and os.path.exists(REF)), reason="oracle/_ref not built (needs the reference tree)")
+@pytest.mark.parametrize("name", ["queens8", "queens16", "queens64", "queens128", "ref_sudoku", "sudoku9_s7"])
+def test_the_references_own_failure_chain_makes_the_search_call_for_call_the_references(name, tmp_path):
+    """CSOLVE_DROPIN_CHAIN=reference: every failing node is walked once more in the reference's depth-first order on
+    the device (csgpu_propagate_one_chain), which bumps exactly the variables the reference bumps and counts its
+    narrowings -- the driver's DEFAULT-flag search (-f true, -r 100) on the GPU propagator is then the all-CPU
+    reference's, call for call: CALLS, CUTS, PROPS, RESTARTS and the solution (queens-64: 430 calls, 23,760 props;
+    queens-128: 4,045 calls, 14 restarts -- tests/golden/solve_stats.json / the compiled reference run here)"""
+    from csolve_amd import problems
+    if name.startswith("queens"):
+        path = tmp_path / (name + ".txt")
+        path.write_text(problems.queens(int(name[6:])))
+    else:
+        path = golden("problems", name + ".txt")
+    p = subprocess.run([REF, "solve", str(path), "-c", "false"], capture_output=True, text=True, timeout=600)
+    want = json.loads(re.search(r"@STATS (\{.*\})", p.stdout).group(1))
+    want_sol = re.findall(r"SOLUTION: (.*?)BEST: (-?\d+)", p.stdout)
+    stats, used, sol = _run(str(path), ["-c", "false"], env={"CSOLVE_DROPIN_CHAIN": "reference"})
+    for k in ("calls", "cuts", "props", "restarts", "solutions"):
+        assert stats[k] == want[k], (name, k, stats[k], want[k])
+    golden_rows = [r for r in json.load(open(golden("solve_stats.json"))) if r["problem"] == name and r["flags"] == []]
+    if golden_rows and name.startswith("queens"):  # (on queens the driver refuses every conflict: -c true is -c false)
+        for k in ("calls", "cuts", "props", "restarts"):
+            assert stats[k] == golden_rows[0][k], (name, k)
+    p2 = subprocess.run([BIN, "solve", str(path), "-c", "false"], capture_output=True, text=True, timeout=600,
+                        env=dict(os.environ, CSOLVE_DROPIN_CHAIN="reference"))
+    assert re.findall(r"SOLUTION: (.*?)BEST: (-?\d+)", p2.stdout) == want_sol
+
+
+@pytest.mark.skipif(not (os.path.exists(BIN) and os.path.exists(REF)), reason="oracle/_ref not built (needs the reference tree)")
 def test_verdicts_with_conflict_learning_on_random_3sat(tmp_path):
     """24 seeded random 3-SAT instances around the satisfiability threshold (ratio 3.6 to 4.8), the reference's driver
     with all its defaults (-c true) once on its own CPU propagator and once on the GPU propagator: satisfiable or not is

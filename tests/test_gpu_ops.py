@@ -343,3 +343,47 @@ def test_causes_of_one_node():
                 failures += 1
                 assert emptied
         assert failures > 0
+
+
+def test_the_references_own_failure_chain_of_one_node():
+    """csgpu_propagate_one_chain (cs_chain.hip.h: one wavefront walks the reference's depth-first propagation): on the
+    failing nodes of random dives the variables it bumps -- the emptied variable, then the recursion stack, innermost
+    first (propagate.c:33-54) -- and the narrowings made before the failure are exactly the oracle's, which restates
+    that walk on the CPU; consistent nodes come out consistent with the reference's PROPS"""
+    from csolve_amd import problems
+    from csolve_amd.solver import solve_root
+    from oracle.cs_oracle import Model as OModel, Oracle
+    checked_fail = checked_ok = with_chain = 0
+    for text in (problems.queens(8), problems.queens(16), problems.queens(40), problems.queens(64), problems.queens(128),
+                 problems.sudoku(3, 0.3, 2), problems.offsets(20, 12, 3)):
+        gm = solve_root(text)
+        om = OModel.parse(text)
+        om.set_domains(gm.domains())
+        om.normalize()
+        om.index()
+        assert om.n_clauses == gm.n_clauses
+        orc = Oracle(om)
+        rng = np.random.default_rng(17)
+        n = gm.n_vars
+        for walk in range(12):
+            dom = np.ascontiguousarray(gm.domains())
+            for depth in range(n):
+                open_vars = np.flatnonzero(dom[:, 0] != dom[:, 1])
+                if len(open_vars) == 0:
+                    break
+                v = int(rng.choice(open_vars))
+                # bounds fail more often than interior values: try both kinds
+                val = int(dom[v, 0]) if rng.integers(3) == 0 else int(rng.integers(dom[v, 0], dom[v, 1] + 1))
+                st, out = orc.instance(dom, v, val, val)
+                want = orc.bumps()
+                g_st, g_props, g_bumps = gm.propagate_one_chain(dom, v, val, val)
+                assert (g_st < 0) == (st < 0), (text[:20], walk, depth, v, val)
+                assert g_props == orc.props(), (text[:20], walk, depth, v, val, g_props, orc.props())
+                assert g_bumps.tolist() == want.tolist(), (text[:20], walk, depth, v, val, g_bumps.tolist(), want.tolist())
+                if st < 0:
+                    checked_fail += 1
+                    with_chain += len(want) > 1
+                    break
+                checked_ok += 1
+                dom = out
+    assert checked_fail >= 40 and checked_ok >= 200 and with_chain >= 10, (checked_fail, checked_ok, with_chain)

@@ -2020,6 +2020,10 @@ static int chain_build(csgpu_model *m) {
   if (cl == NULL) return -1;
   for (int32_t c = 0; c < h->n_clauses; c++) {
     const cs_node *top = &h->nodes[h->clause_node[c]];
+    if (top->op == CS_OP_CONST) { /* a constant element of the root (a folded bound): in no variable's list */
+      cl[c].lx = -1; cl[c].lc = 0; cl[c].rx = -1; cl[c].rc = 0;
+      continue;
+    }
     int ok = top->op == CS_OP_NOT && h->nodes[top->a].op == CS_OP_EQ;
     if (ok) {
       const cs_node *eq = &h->nodes[top->a];

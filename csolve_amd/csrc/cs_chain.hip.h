@@ -93,7 +93,7 @@ __global__ __launch_bounds__(64) void cs_ne_chain(int n, int n_clauses, const cs
       const bool fresh = valid && (int)tags[c] <= f_tag; /* not revised by a nested (later) call */
       bool acts = false;
       cs_val lval = cs_value(0), rval = cs_value(0);
-      if (fresh) {
+      if (fresh && cl[c].lx >= 0) {
         const cs_chain_clause k = cl[c];
         lval = operand(k.lx, k.lc);
         rval = operand(k.rx, k.rc);

@@ -154,39 +154,31 @@ __device__ __forceinline__ void cs_allowed_values(unsigned long long forb, int r
   *a_hi = x_hi;
 }
 
-/* S lanes (a whole wave, or a half or a quarter of one for small models) per parent: the open variable with
- * the smallest interval (ties: lowest index), the reference's "-o smallest-domain" idea (strategy.c:85-91) as a
- * pure function of the state.  Intervals wider than SPLIT_WIDTH are halved (two children) instead of enumerated.
- * The same choice in every lane of the segment.  With n <= S every lane holds one variable: its interval, its
- * set word and its root lower bound are loaded up front (independent, coalesced loads) and the chosen
- * variable's are fetched from its lane -- no load depends on the outcome of the reduction. */
+/* What a lane found among ITS variables (v = sl, sl + S, ...): the smallest key and that variable's interval.  Scan and
+ * pick are separate so that a caller can have the rows of several parents in flight before it reduces any of them. */
+struct cs_branch_part {
+  unsigned long long best;
+  cs_val d;
+};
+
 template <int S>
-__device__ __forceinline__ cs_choice cs_branch_seg(const cs_val *__restrict__ row, long long row_index, int n, int sl,
-                                                   const cs_holes &H) {
-  const bool one_each = n <= S;
-  /* key = (width-1) * 2^32 + index, minimised over the segment */
-  unsigned long long best = ~0ull;
-  cs_val mine = cs_value(0);
-  unsigned long long my_forb = 0ull;
-  int my_root = 0;
-  if (one_each) {
-    if (sl < n) {
-      mine = row[sl];
-      if (H.pool_forb != nullptr) {
-        my_forb = H.pool_forb[(size_t)row_index * n + sl];
-        my_root = H.root_lo[sl];
-      }
-      if (mine.lo != mine.hi) best = cs_branch_key(H, mine, sl);
-    }
-  } else {
-    for (int v = sl; v < n; v += S) {
-      const cs_val d = row[v];
-      if (d.lo != d.hi) {
-        const unsigned long long key = cs_branch_key(H, d, v);
-        best = key < best ? key : best;
-      }
+__device__ __forceinline__ cs_branch_part cs_branch_scan(const cs_val *__restrict__ row, int n, int sl, const cs_holes &H) {
+  cs_branch_part p;
+  p.best = ~0ull;
+  p.d = cs_value(0);
+  for (int v = sl; v < n; v += S) {
+    const cs_val d = row[v];
+    if (d.lo != d.hi) {
+      const unsigned long long key = cs_branch_key(H, d, v);
+      if (key < p.best) { p.best = key; p.d = d; }
     }
   }
+  return p;
+}
+
+template <int S>
+__device__ __forceinline__ cs_choice cs_branch_pick(cs_branch_part p, long long row_index, int n, const cs_holes &H) {
+  unsigned long long best = p.best;
   for (int o = S / 2; o > 0; o >>= 1) {
     const unsigned long long other = __shfl_xor(best, o);
     best = other < best ? other : best;
@@ -195,23 +187,15 @@ __device__ __forceinline__ cs_choice cs_branch_seg(const cs_val *__restrict__ ro
   c.var = -1; c.lo = 0; c.hi = 0; c.count = 0; c.a_lo = 0u; c.a_hi = 0u; c.holes = 0; c.skipped = 0;
   if (best == ~0ull) return c;
   const int var = (int)(best & 0xffffu);
+  /* the lane that scanned the variable (v = sl + k S, so sl = var mod S) holds its interval: no second look at the row */
   cs_val d;
+  d.lo = __shfl(p.d.lo, var & (S - 1), S);
+  d.hi = __shfl(p.d.hi, var & (S - 1), S);
   unsigned long long forb = 0ull;
   int root = 0;
-  if (one_each) { /* from the lane that holds the variable (segment-relative source lane) */
-    d.lo = __shfl(mine.lo, var, S);
-    d.hi = __shfl(mine.hi, var, S);
-    if (H.pool_forb != nullptr) {
-      forb = ((unsigned long long)(unsigned)__shfl((int)(my_forb >> 32), var, S) << 32) |
-             (unsigned long long)(unsigned)__shfl((int)(unsigned)my_forb, var, S);
-      root = __shfl(my_root, var, S);
-    }
-  } else {
-    d = row[var];
-    if (H.pool_forb != nullptr) {
-      forb = H.pool_forb[(size_t)row_index * n + var];
-      root = H.root_lo[var];
-    }
+  if (H.pool_forb != nullptr) {
+    forb = H.pool_forb[(size_t)row_index * n + var];
+    root = H.root_lo[var];
   }
   const long long width = (long long)d.hi - (long long)d.lo + 1;
   c.var = var;
@@ -227,6 +211,16 @@ __device__ __forceinline__ cs_choice cs_branch_seg(const cs_val *__restrict__ ro
     c.count = allowed;
   }
   return c;
+}
+
+/* S lanes (a whole wave, or a half or a quarter of one for small models) per parent: the open variable the branching
+ * rule puts first (cs_branch_key: by default the smallest interval, ties lowest index -- the reference's
+ * "-o smallest-domain" idea, strategy.c:85-91, as a pure function of the state).  Intervals wider than SPLIT_WIDTH are
+ * halved (two children) instead of enumerated.  The same choice in every lane of the segment. */
+template <int S>
+__device__ __forceinline__ cs_choice cs_branch_seg(const cs_val *__restrict__ row, long long row_index, int n, int sl,
+                                                   const cs_holes &H) {
+  return cs_branch_pick<S>(cs_branch_scan<S>(row, n, sl, H), row_index, n, H);
 }
 
 /* a workgroup takes SB / S consecutive parents; besides var and count per parent it leaves the number of
@@ -483,10 +477,21 @@ __global__ __launch_bounds__(1024) void cs_expand_small(const cs_val *__restrict
   __shared__ int s_off[SMALL_PARENTS];
   __shared__ long long s_part[16];
   if (threadIdx.x < C_PER_ITERATION) counters[threadIdx.x] = 0ull;
-  /* sixteen lanes per parent: all (at most 256) parents of the iteration in four passes of the workgroup */
-  for (int p = (int)threadIdx.x >> 4; p < parents; p += 64) {
-    const cs_choice c = cs_branch_seg<16>(pool + (size_t)(first_row + p) * n, first_row + p, n, (int)threadIdx.x & 15, H);
-    if ((threadIdx.x & 15) == 0) s_choice[p] = c;
+  /* sixteen lanes per parent, 64 parents per pass of the workgroup, four passes' rows in flight at a time (measured
+   * no faster than one pass at a time: 1,024 parent rows are 300 KB through ONE CU, ~25 GB/s -- 12 us whatever the order) */
+  for (int p0 = (int)threadIdx.x >> 4; p0 < parents; p0 += 256) {
+    cs_branch_part part[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int p = p0 + 64 * k < parents ? p0 + 64 * k : parents - 1;
+      part[k] = cs_branch_scan<16>(pool + (size_t)(first_row + p) * n, n, (int)threadIdx.x & 15, H);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int p = p0 + 64 * k;
+      const cs_choice c = cs_branch_pick<16>(part[k], first_row + (p < parents ? p : parents - 1), n, H);
+      if ((threadIdx.x & 15) == 0 && p < parents) s_choice[p] = c;
+    }
   }
   __syncthreads();
   long long total, skipped_total;
@@ -596,7 +601,9 @@ __global__ __launch_bounds__(1024) void cs_classify_small(const csgpu_result *__
   const int children = (int)counters[C_TOTAL_CHILDREN];
   long long carry = 0; /* survivors in the low half, complete children in the high half: one scan for both */
   long long cuts = 0, props = 0, revs = 0; /* per thread, reduced once at the end */
-  constexpr int PER = 4; /* consecutive children per thread and tile */
+  /* consecutive children per thread and tile (sixteen, so that a MIN iteration of 10,000 children is one tile, was
+   * measured no faster: this single workgroup is bound by what ONE CU reads, ~25 GB/s -- 160 KB of results are 7 us) */
+  constexpr int PER = 4;
   for (int base = 0; base < children; base += 1024 * PER) {
     const int first = base + (int)threadIdx.x * PER;
     int status[PER];
@@ -797,10 +804,21 @@ __global__ __launch_bounds__(1024) void cs_expand_burst(const cs_val *__restrict
   const int low_values_last = objective == CS_OBJ_MAX ? 0 : 1;
   const unsigned scramble =
       objective == CS_OBJ_ANY ? (unsigned)((unsigned long long)s_iter * 2654435761ull + 0x9e3779b9u) | 1u : 0u;
-  /* sixteen lanes per parent: all (at most 256) parents of the iteration in four passes of the workgroup */
-  for (int p = (int)threadIdx.x >> 4; p < parents; p += 64) {
-    const cs_choice c = cs_branch_seg<16>(pool + (size_t)(first_row + p) * n, first_row + p, n, (int)threadIdx.x & 15, H);
-    if ((threadIdx.x & 15) == 0) s_choice[p] = c;
+  /* sixteen lanes per parent, 64 parents per pass of the workgroup, four passes' rows in flight at a time (measured
+   * no faster than one pass at a time: 1,024 parent rows are 300 KB through ONE CU, ~25 GB/s -- 12 us whatever the order) */
+  for (int p0 = (int)threadIdx.x >> 4; p0 < parents; p0 += 256) {
+    cs_branch_part part[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int p = p0 + 64 * k < parents ? p0 + 64 * k : parents - 1;
+      part[k] = cs_branch_scan<16>(pool + (size_t)(first_row + p) * n, n, (int)threadIdx.x & 15, H);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int p = p0 + 64 * k;
+      const cs_choice c = cs_branch_pick<16>(part[k], first_row + (p < parents ? p : parents - 1), n, H);
+      if ((threadIdx.x & 15) == 0 && p < parents) s_choice[p] = c;
+    }
   }
   __syncthreads();
   long long total, skipped_total;

@@ -12,7 +12,11 @@ SPLIT_WIDTH = 256
 
 
 class OracleEngine:
-    def __init__(self, omodel, parents_per_iteration=4):
+    def __init__(self, omodel, parents_per_iteration=4, shuffle_seed=None):
+        """shuffle_seed: permute the pool after every iteration with this seed -- the level kernels of the GPU engine
+        (cs_step.hip.h) leave a frontier's survivors in an order that depends on timing, so two ranks that expand the same
+        root hold the same SET of open states in different orders"""
+        self.rng = None if shuffle_seed is None else np.random.default_rng(shuffle_seed)
         self.m = omodel
         self.orc = Oracle(omodel)
         self.objective = omodel.view.objective
@@ -96,6 +100,9 @@ class OracleEngine:
                     else:
                         self.pool.append(out)
             self.st["pool_peak"] = max(self.st["pool_peak"], len(self.pool))
+            if self.rng is not None and len(self.pool) > 1:
+                order = self.rng.permutation(len(self.pool))
+                self.pool = [self.pool[i] for i in order]
         self.st["pool"] = len(self.pool)
         self.st["done"] = int(not self.pool or (self.objective == OBJ_ANY and self.st["solutions"] > 0))
         return dict(self.st)

@@ -48,9 +48,11 @@ def _worker(rank, world, port, text, out_q, options=None):
     assert o0.propagate(om.root, om.n_vars) >= 0
     om.set_domains(o0.domains())
     om.index()
-    eng = OracleEngine(om)
+    options = dict(options or {})
+    shuffle = options.pop("engine_shuffle", None)
+    eng = OracleEngine(om, shuffle_seed=None if shuffle is None else shuffle + rank)
     sh = ShardedSearch(eng, om.view.objective, om.n_vars, rank, world, dist, engine_device="cpu",
-                       **dict(dict(slice_iterations=8, seed_states_per_rank=4, low_water=4), **(options or {})))
+                       **dict(dict(slice_iterations=8, seed_states_per_rank=4, low_water=4), **options))
     root = torch.from_numpy(om.domains()).unsqueeze(0).contiguous()
     local, totals = sh.run(root)
     assert sh.seconds["total"] >= sh.seconds["busy"] > 0 and 0.0 <= sh.idle_fraction() <= 1.0
@@ -105,6 +107,21 @@ def test_sharded_search_without_the_page_and_with_rank0_seeding():
     res = _run(3, text, dict(slice_iterations=1 << 20, poll_iterations=2))
     assert all(r[4] == 92 for r in res) and res[0][3] == single[0][3]
     assert sum(r[8] for r in res) > 0, "nobody answered a dry rank's call"
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_whose_frontiers_are_ordered_differently_fall_back_to_rank_zeros(world):
+    """engines that leave a frontier in a timing-dependent order (the GPU engine's level kernels do): every rank expands
+    the root to the same SET of open states in its own order, the checksums differ, rank 0's frontier is broadcast and
+    the ranks take their shares of THAT -- no subtree is walked twice or left out: the single-engine tree, 92 solutions"""
+    from csolve_amd import problems
+    text = problems.queens(8, "ALL")
+    single = _run(1, text)
+    res = _run(world, text, dict(engine_shuffle=1234))
+    assert all(r[4] == 92 for r in res) and sum(r[2] for r in res) == 92
+    assert res[0][3] == single[0][3], "a subtree was walked twice or not at all"
+    assert not any(r[7] for r in res), "differently ordered frontiers must not pass for the same"
+    assert all(r[1] > 0 for r in res)
 
 
 def test_sharded_minimisation_shares_the_incumbent():

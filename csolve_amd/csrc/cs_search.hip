@@ -58,8 +58,13 @@ struct cs_choice {
 
 /* state of the device-driven iterations, in device memory between the kernels of a burst */
 enum { B_TOP = 0, B_BUDGET, B_LIMIT, B_LIMIT_MAX, B_ITER_BASE, B_ITERS, B_NODES, B_CUTS, B_PROPS, B_REVS, B_PEAK, B_ERROR,
-       B_SCATTER_BASE, B_IMPROVED, B_COUNT };
+       B_SCATTER_BASE, B_IMPROVED, B_D_PARENTS, B_D_FIRST, B_D_ITER /* the iteration cs_burst_branch decided on */, B_COUNT };
 #define BURST_ITERATIONS 16
+/* a MIN / MAX iteration's bookkeeping is spread over this many workgroups (one workgroup is bound by what ONE CU
+ * reads, ~25 GB/s: 1,024 parent rows took it 24 us, 10,000 results 18 us) */
+#define BURST_WGS 16
+#define BURST_PPW (SMALL_PARENTS / BURST_WGS) /* parents per workgroup: sixteen lanes each, one pass */
+#define BURST_CLASS_WGS 32
 
 struct csgpu_search {
   const csgpu_model *m;
@@ -124,6 +129,8 @@ struct csgpu_search {
   int burst_off;       /* CSGPU_SEARCH_BURST=0: every iteration driven from the host */
   int eval_always;     /* CSGPU_SEARCH_EVAL=1: complete children of pure != networks are evaluated all the same (tests) */
   int graph_off;       /* CSGPU_SEARCH_GRAPH=0: the launches of a burst enqueued one by one */
+  int burst_split;     /* MIN / MAX: expansion and classification of a device-driven iteration by several workgroups
+                        * (CSGPU_SEARCH_BURST_SPLIT=0: by one, as ANY) */
 };
 
 extern "C" int csgpu_internal_set_error(int code, const char *msg); /* cs_capi.hip */
@@ -751,6 +758,39 @@ __global__ __launch_bounds__(256) void cs_accept_burst(const cs_val *__restrict_
   if (threadIdx.x == 0) counters[C_COMPLETE] = 0ull; /* accepted: the next burst's first expansion must not do it again */
 }
 
+/* the head of a device-driven iteration -- how many parents, from which row -- as a function of `burst` alone, so
+ * that every workgroup of a split expansion can decide it for itself */
+struct cs_burst_head {
+  int parents, error;
+  long long first_row, iter;
+};
+__device__ __forceinline__ cs_burst_head cs_burst_decide(const unsigned long long *__restrict__ burst, bool done,
+                                                         long long max_width, long long cap, long long room_limit) {
+  cs_burst_head h;
+  h.error = 0;
+  const long long top = (long long)burst[B_TOP];
+  /* a few parents while the pool is small (dive for a solution / an incumbent first), more once there is a
+   * backlog of open states: 1/16 of the pool, within [B_LIMIT, B_LIMIT_MAX] (schedule-10: 0.7 s instead of 1.6 s
+   * with 64 throughout; small searches lose a few ms) */
+  long long limit = top / 16;
+  limit = limit < (long long)burst[B_LIMIT] ? (long long)burst[B_LIMIT] : limit;
+  limit = limit > (long long)burst[B_LIMIT_MAX] ? (long long)burst[B_LIMIT_MAX] : limit;
+  long long parents = top < limit ? top : limit;
+  if (burst[B_BUDGET] == 0ull || burst[B_ERROR] != 0ull || done) parents = 0;
+  if (parents > 0 && top - parents + parents * max_width > room_limit) { /* as one_iteration */
+    const long long fit = max_width > 1 ? (room_limit - top) / (max_width - 1) : parents;
+    parents = fit < 1 ? 1 : (fit < parents ? fit : parents);
+    if (top - parents + parents * max_width > cap) {
+      h.error = 1;
+      parents = 0;
+    }
+  }
+  h.parents = (int)parents;
+  h.first_row = top - parents;
+  h.iter = (long long)(burst[B_ITER_BASE] + burst[B_ITERS]);
+  return h;
+}
+
 /* ---- device-driven iterations: what the host does around a small iteration, on the device ----
  * cs_expand_burst = the head of one_iteration (how many parents, does it fit) + cs_expand_small; the pool top,
  * the iteration budget and the running totals are in `burst`.  An iteration with nothing to do (pool empty,
@@ -774,27 +814,11 @@ __global__ __launch_bounds__(1024) void cs_expand_burst(const cs_val *__restrict
   cs_accept_block(child_states, complete_list, truth, n, objective, obj_var, counters, burst, solutions, max_solutions,
                   best_solution, best);
   if (threadIdx.x == 0) {
-    const long long top = (long long)burst[B_TOP];
-    /* a few parents while the pool is small (dive for a solution / an incumbent first), more once there is a
-     * backlog of open states: 1/16 of the pool, within [B_LIMIT, B_LIMIT_MAX] (schedule-10: 0.7 s instead of 1.6 s
-     * with 64 throughout; small searches lose a few ms) */
-    long long limit = top / 16;
-    limit = limit < (long long)burst[B_LIMIT] ? (long long)burst[B_LIMIT] : limit;
-    limit = limit > (long long)burst[B_LIMIT_MAX] ? (long long)burst[B_LIMIT_MAX] : limit;
-    long long parents = top < limit ? top : limit;
-    if (burst[B_BUDGET] == 0ull || burst[B_ERROR] != 0ull || (objective == CS_OBJ_ANY && counters[C_STORED] != 0ull))
-      parents = 0;
-    if (parents > 0 && top - parents + parents * max_width > room_limit) { /* as one_iteration */
-      const long long fit = max_width > 1 ? (room_limit - top) / (max_width - 1) : parents;
-      parents = fit < 1 ? 1 : (fit < parents ? fit : parents);
-      if (top - parents + parents * max_width > cap) {
-        burst[B_ERROR] = 1ull;
-        parents = 0;
-      }
-    }
-    s_parents = (int)parents;
-    s_first = top - parents;
-    s_iter = (long long)(burst[B_ITER_BASE] + burst[B_ITERS]);
+    const cs_burst_head h = cs_burst_decide(burst, objective == CS_OBJ_ANY && counters[C_STORED] != 0ull, max_width, cap, room_limit);
+    if (h.error) burst[B_ERROR] = 1ull;
+    s_parents = h.parents;
+    s_first = h.first_row;
+    s_iter = h.iter;
   }
   if (threadIdx.x < C_PER_ITERATION) counters[threadIdx.x] = 0ull;
   __syncthreads();
@@ -838,6 +862,200 @@ __global__ __launch_bounds__(1024) void cs_expand_burst(const cs_val *__restrict
   __syncthreads();
   for (int p = (int)threadIdx.x >> 4; p < parents; p += 64)
     cs_emit_seg<16>(s_choice[p], first_row + p, s_off[p], nodes, low_values_last, scramble, (int)threadIdx.x & 15);
+}
+
+/* ---- the same iteration by BURST_WGS workgroups (MIN / MAX, whose iterations take up to 1,024 parents) ----
+ * cs_burst_branch: workgroup g chooses for parents [64 g, 64 g + 64) and leaves their child counts' sum; workgroup 0
+ * also runs the previous iteration's accept and publishes the head.  Nothing any workgroup READS to decide the head
+ * is written here (the accept touches the incumbent, the solution counters and B_IMPROVED only), so all of them
+ * decide alike without waiting for one another.
+ * cs_burst_emit: workgroup g adds up its predecessors' sums (sixteen numbers) and writes its parents' children;
+ * workgroup 0 moves the pool top and the running totals.  Same nodes in the same places as cs_expand_burst. */
+__global__ __launch_bounds__(1024) void cs_burst_branch(const cs_val *__restrict__ pool, int n,
+                                                        unsigned long long *__restrict__ counters,
+                                                        unsigned long long *__restrict__ burst, int objective,
+                                                        long long max_width, long long cap, long long room_limit,
+                                                        cs_holes H, cs_choice *__restrict__ choice,
+                                                        int *__restrict__ wg_sum, int *__restrict__ wg_skip,
+                                                        const cs_val *__restrict__ child_states,
+                                                        const int *__restrict__ complete_list,
+                                                        const int *__restrict__ truth, int obj_var,
+                                                        int32_t *__restrict__ solutions, long long max_solutions,
+                                                        int32_t *__restrict__ best_solution, int *__restrict__ best) {
+  __shared__ int s_cnt[BURST_PPW], s_skip[BURST_PPW];
+  __shared__ long long s_first;
+  __shared__ int s_parents;
+  const int g = (int)blockIdx.x;
+  if (g == 0) /* uniform within the workgroup */
+    cs_accept_block(child_states, complete_list, truth, n, objective, obj_var, counters, burst, solutions, max_solutions,
+                    best_solution, best);
+  if (threadIdx.x == 0) {
+    const cs_burst_head h = cs_burst_decide(burst, false, max_width, cap, room_limit);
+    s_parents = h.parents;
+    s_first = h.first_row;
+    if (g == 0) {
+      if (h.error) burst[B_ERROR] = 1ull;
+      burst[B_D_PARENTS] = (unsigned long long)h.parents;
+      burst[B_D_FIRST] = (unsigned long long)h.first_row;
+      burst[B_D_ITER] = (unsigned long long)h.iter;
+    }
+  }
+  if (g == 0 && threadIdx.x < C_PER_ITERATION) counters[threadIdx.x] = 0ull;
+  __syncthreads();
+  const int parents = s_parents;
+  const int p = g * BURST_PPW + ((int)threadIdx.x >> 4);
+  if (g * BURST_PPW >= parents) { /* uniform */
+    if (threadIdx.x == 0) { wg_sum[g] = 0; wg_skip[g] = 0; }
+    return;
+  }
+  const long long first_row = s_first;
+  const int pc = p < parents ? p : parents - 1;
+  const cs_choice c = cs_branch_seg<16>(pool + (size_t)(first_row + pc) * n, first_row + pc, n, (int)threadIdx.x & 15, H);
+  if ((threadIdx.x & 15) == 0) {
+    if (p < parents) choice[p] = c;
+    s_cnt[threadIdx.x >> 4] = p < parents ? c.count : 0;
+    s_skip[threadIdx.x >> 4] = p < parents ? c.skipped : 0;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    int cnt = s_cnt[threadIdx.x], skip = s_skip[threadIdx.x];
+    for (int o = 32; o > 0; o >>= 1) { cnt += __shfl_xor(cnt, o); skip += __shfl_xor(skip, o); }
+    if (threadIdx.x == 0) { wg_sum[g] = cnt; wg_skip[g] = skip; }
+  }
+}
+
+__global__ __launch_bounds__(1024) void cs_burst_emit(csgpu_node *__restrict__ nodes,
+                                                      unsigned long long *__restrict__ counters,
+                                                      unsigned long long *__restrict__ burst, int objective,
+                                                      const cs_choice *__restrict__ choice,
+                                                      const int *__restrict__ wg_sum, const int *__restrict__ wg_skip) {
+  __shared__ cs_choice s_choice[BURST_PPW];
+  __shared__ int s_off[BURST_PPW];
+  const int g = (int)blockIdx.x;
+  const int parents = (int)burst[B_D_PARENTS];
+  if (g * BURST_PPW >= parents) return; /* uniform; parents == 0: the counters are zero already, nothing moves */
+  const long long first_row = (long long)burst[B_D_FIRST];
+  const long long iter = (long long)burst[B_D_ITER];
+  if (threadIdx.x < 64) {
+    const int t = (int)threadIdx.x, p = g * BURST_PPW + t;
+    cs_choice c;
+    c.var = -1; c.lo = 0; c.hi = 0; c.count = 0; c.a_lo = 0u; c.a_hi = 0u; c.holes = 0; c.skipped = 0;
+    if (p < parents) c = choice[p];
+    s_choice[t] = c;
+    /* the children before this workgroup's parents, then before this parent */
+    int before = t < g ? wg_sum[t] : 0;
+    int all = t < BURST_WGS ? wg_sum[t] : 0, all_skip = t < BURST_WGS ? wg_skip[t] : 0;
+    int incl = c.count;
+    for (int d = 1; d < 64; d <<= 1) {
+      const int up = __shfl_up(incl, d);
+      if (t >= d) incl += up;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      before += __shfl_xor(before, o);
+      all += __shfl_xor(all, o);
+      all_skip += __shfl_xor(all_skip, o);
+    }
+    s_off[t] = before + incl - c.count;
+    if (g == 0 && t == 0) {
+      counters[C_TOTAL_CHILDREN] = (unsigned long long)all;
+      counters[C_SKIPPED] = (unsigned long long)all_skip;
+      burst[B_TOP] = (unsigned long long)first_row;
+      burst[B_ITERS] += 1ull;
+      burst[B_BUDGET] -= 1ull;
+      burst[B_NODES] += (unsigned long long)((long long)all + all_skip);
+      burst[B_CUTS] += (unsigned long long)all_skip;
+    }
+  }
+  __syncthreads();
+  const int low_values_last = objective == CS_OBJ_MAX ? 0 : 1;
+  const unsigned scramble =
+      objective == CS_OBJ_ANY ? (unsigned)((unsigned long long)iter * 2654435761ull + 0x9e3779b9u) | 1u : 0u;
+  const int q = (int)threadIdx.x >> 4;
+  if (g * BURST_PPW + q < parents)
+    cs_emit_seg<16>(s_choice[q], first_row + g * BURST_PPW + q, s_off[q], nodes, low_values_last, scramble, (int)threadIdx.x & 15);
+}
+
+/* cs_classify_small by BURST_CLASS_WGS workgroups: cs_burst_count leaves each workgroup's class counts (its share is
+ * children / BURST_CLASS_WGS consecutive children), cs_burst_assign adds up its predecessors' and writes the lists in
+ * child order; its workgroup 0 moves the pool top and the totals. */
+__device__ __forceinline__ void cs_burst_share(int children, int g, int *beg, int *end) {
+  const int chunk = (children + BURST_CLASS_WGS - 1) / BURST_CLASS_WGS;
+  const long long b = (long long)g * chunk, e = b + chunk;
+  *beg = b < children ? (int)b : children;
+  *end = e < children ? (int)e : children;
+}
+
+__global__ __launch_bounds__(1024) void cs_burst_count(const csgpu_result *__restrict__ res,
+                                                       const unsigned long long *__restrict__ counters,
+                                                       int *__restrict__ wg_surv, int *__restrict__ wg_comp,
+                                                       int *__restrict__ wg_cuts, int *__restrict__ wg_props,
+                                                       int *__restrict__ wg_revs) {
+  __shared__ long long s_part[16];
+  int beg, end;
+  cs_burst_share((int)counters[C_TOTAL_CHILDREN], (int)blockIdx.x, &beg, &end);
+  long long classes = 0, cuts = 0, props = 0, revs = 0;
+  for (int i = beg + (int)threadIdx.x; i < end; i += 1024) {
+    const csgpu_result r = res[i];
+    classes += (long long)(r.status > 0) | ((long long)(r.status == 0) << 32);
+    props += r.status >= 0 ? r.props : 0;
+    revs += r.revisions;
+    cuts += r.status == -1;
+  }
+  long long t_classes, t_cuts, t_props, t_revs;
+  (void)cs_block_excl_scan(classes, s_part, &t_classes);
+  (void)cs_block_excl_scan(cuts, s_part, &t_cuts);
+  (void)cs_block_excl_scan(props, s_part, &t_props);
+  (void)cs_block_excl_scan(revs, s_part, &t_revs);
+  if (threadIdx.x == 0) {
+    wg_surv[blockIdx.x] = (int)(t_classes & 0xffffffffll);
+    wg_comp[blockIdx.x] = (int)(t_classes >> 32);
+    wg_cuts[blockIdx.x] = (int)t_cuts;
+    wg_props[blockIdx.x] = (int)t_props;
+    wg_revs[blockIdx.x] = (int)t_revs;
+  }
+}
+
+__global__ __launch_bounds__(1024) void cs_burst_assign(const csgpu_result *__restrict__ res,
+                                                        int *__restrict__ surv_list, int *__restrict__ complete_list,
+                                                        unsigned long long *__restrict__ counters,
+                                                        unsigned long long *__restrict__ burst,
+                                                        const int *__restrict__ wg_surv, const int *__restrict__ wg_comp,
+                                                        const int *__restrict__ wg_cuts, const int *__restrict__ wg_props,
+                                                        const int *__restrict__ wg_revs) {
+  __shared__ long long s_part[16];
+  const int g = (int)blockIdx.x;
+  int beg, end;
+  cs_burst_share((int)counters[C_TOTAL_CHILDREN], g, &beg, &end);
+  long long carry = 0; /* survivors | complete children << 32 before this workgroup's share */
+  for (int h = 0; h < g; h++) carry += (long long)wg_surv[h] | ((long long)wg_comp[h] << 32);
+  for (int base = beg; base < end; base += 1024) {
+    const int i = base + (int)threadIdx.x;
+    const int status = i < end ? res[i].status : -2;
+    const long long x = (long long)(status > 0) | ((long long)(status == 0) << 32);
+    long long total;
+    const long long ex = carry + cs_block_excl_scan(x, s_part, &total);
+    if (status > 0) surv_list[ex & 0xffffffffll] = i;
+    if (status == 0) complete_list[ex >> 32] = i;
+    carry += total;
+  }
+  if (g == 0 && threadIdx.x == 0) {
+    long long surv = 0, comp = 0, cuts = 0, props = 0, revs = 0;
+    for (int h = 0; h < BURST_CLASS_WGS; h++) {
+      surv += wg_surv[h]; comp += wg_comp[h]; cuts += wg_cuts[h]; props += wg_props[h]; revs += wg_revs[h];
+    }
+    counters[C_SURVIVORS] = (unsigned long long)surv;
+    counters[C_COMPLETE] = (unsigned long long)comp;
+    counters[C_CUTS] = (unsigned long long)cuts;
+    counters[C_PROPS] = (unsigned long long)props;
+    counters[C_REVS] = (unsigned long long)revs;
+    const unsigned long long base = burst[B_TOP], top = base + (unsigned long long)surv;
+    burst[B_SCATTER_BASE] = base;
+    burst[B_TOP] = top;
+    if (top > burst[B_PEAK]) burst[B_PEAK] = top;
+    burst[B_CUTS] += (unsigned long long)cuts;
+    burst[B_PROPS] += (unsigned long long)props;
+    burst[B_REVS] += (unsigned long long)revs;
+  }
 }
 
 /* copy survivor k (child surv_list[k]) into pool row new_top + k: a workgroup takes cpb (at most SB) consecutive
@@ -1130,7 +1348,8 @@ extern "C" int csgpu_search_create(const csgpu_model *m, int64_t pool_capacity, 
   ALLOC(s->d_complete_list, sizeof(int) * (size_t)max_children);
   ALLOC(s->d_truth, sizeof(int) * (size_t)max_children);
   {
-    const size_t blocks = ((size_t)max_children + SB - 1) / SB + 1;
+    size_t blocks = ((size_t)max_children + SB - 1) / SB + 1;
+    if (blocks < BURST_CLASS_WGS) blocks = BURST_CLASS_WGS;
     ALLOC(s->d_block_surv, sizeof(int) * blocks);
     ALLOC(s->d_block_comp, sizeof(int) * blocks);
     ALLOC(s->d_block_cuts, sizeof(int) * blocks);
@@ -1161,6 +1380,8 @@ extern "C" int csgpu_search_create(const csgpu_model *m, int64_t pool_capacity, 
   {
     const char *e = getenv("CSGPU_SEARCH_BURST");
     s->burst_off = e != NULL && e[0] == '0';
+    const char *es = getenv("CSGPU_SEARCH_BURST_SPLIT");
+    s->burst_split = !(es != NULL && es[0] == '0');
     const char *ev = getenv("CSGPU_SEARCH_EVAL");
     s->eval_always = ev != NULL && ev[0] == '1';
     e = getenv("CSGPU_SEARCH_GRAPH");
@@ -1712,11 +1933,23 @@ static int enqueue_burst(csgpu_search *s, hipStream_t st) {
   int cpb = 4096 / n;
   cpb = cpb < 4 ? 4 : (cpb > SB ? SB : cpb);
   while (cpb > 4 && bound / cpb < 2048) cpb >>= 1;
+  /* ANY dives with few parents and must see the accept before it decides: one workgroup */
+  const int split = s->burst_split && s->objective != CS_OBJ_ANY;
   for (int it = 0; it < BURST_ITERATIONS; it++) {
-    hipLaunchKernelGGL(cs_expand_burst, dim3(1), dim3(1024), 0, st, s->pool, n, s->d_nodes, s->d_counters, s->d_burst,
-                       s->objective, (long long)s->max_width, (long long)s->cap, room_limit, s->holes,
-                       (const cs_val *)s->d_child_states, (const int *)s->d_complete_list, (const int *)s->d_truth,
-                       s->obj_var, s->d_solutions, (long long)s->max_solutions, s->d_best_solution, s->d_best);
+    if (split) {
+      hipLaunchKernelGGL(cs_burst_branch, dim3(BURST_WGS), dim3(1024), 0, st, s->pool, n, s->d_counters, s->d_burst,
+                         s->objective, (long long)s->max_width, (long long)s->cap, room_limit, s->holes, s->d_choice,
+                         s->d_block_sum, s->d_block_skip, (const cs_val *)s->d_child_states,
+                         (const int *)s->d_complete_list, (const int *)s->d_truth, s->obj_var, s->d_solutions,
+                         (long long)s->max_solutions, s->d_best_solution, s->d_best);
+      hipLaunchKernelGGL(cs_burst_emit, dim3(BURST_WGS), dim3(1024), 0, st, s->d_nodes, s->d_counters, s->d_burst,
+                         s->objective, (const cs_choice *)s->d_choice, (const int *)s->d_block_sum,
+                         (const int *)s->d_block_skip);
+    } else
+      hipLaunchKernelGGL(cs_expand_burst, dim3(1), dim3(1024), 0, st, s->pool, n, s->d_nodes, s->d_counters, s->d_burst,
+                         s->objective, (long long)s->max_width, (long long)s->cap, room_limit, s->holes,
+                         (const cs_val *)s->d_child_states, (const int *)s->d_complete_list, (const int *)s->d_truth,
+                         s->obj_var, s->d_solutions, (long long)s->max_solutions, s->d_best_solution, s->d_best);
     int rc;
     if (s->fw > 0)
       rc = csgpu_internal_propagate_fb(s->m, (const csgpu_val *)s->pool, (const uint64_t *)s->pool_forb, s->d_nodes,
@@ -1731,8 +1964,17 @@ static int enqueue_burst(csgpu_search *s, hipStream_t st) {
       hipLaunchKernelGGL(cs_prio_update, dim3((unsigned)((bound + SB - 1) / SB)), dim3(SB), 0, st, (const csgpu_result *)s->d_results,
                          (const csgpu_node *)s->d_nodes, (int)bound, (const unsigned long long *)d_children, n, s->fail_var_known,
                          s->d_prio);
-    hipLaunchKernelGGL(cs_classify_small, dim3(1), dim3(1024), 0, st, s->d_results, s->d_dest, s->d_complete_list,
-                       s->d_counters, s->d_burst);
+    if (split) {
+      hipLaunchKernelGGL(cs_burst_count, dim3(BURST_CLASS_WGS), dim3(1024), 0, st, (const csgpu_result *)s->d_results,
+                         (const unsigned long long *)s->d_counters, s->d_block_surv, s->d_block_comp, s->d_block_cuts,
+                         s->d_block_props, s->d_block_revs);
+      hipLaunchKernelGGL(cs_burst_assign, dim3(BURST_CLASS_WGS), dim3(1024), 0, st, (const csgpu_result *)s->d_results,
+                         s->d_dest, s->d_complete_list, s->d_counters, s->d_burst, (const int *)s->d_block_surv,
+                         (const int *)s->d_block_comp, (const int *)s->d_block_cuts, (const int *)s->d_block_props,
+                         (const int *)s->d_block_revs);
+    } else
+      hipLaunchKernelGGL(cs_classify_small, dim3(1), dim3(1024), 0, st, s->d_results, s->d_dest, s->d_complete_list,
+                         s->d_counters, s->d_burst);
     hipLaunchKernelGGL(cs_scatter, dim3((unsigned)((bound + cpb - 1) / cpb)), dim3(SB), 0, st, s->d_child_states, s->d_dest,
                        s->d_counters, 0ll, n, s->pool, s->d_child_forb, s->pool_forb, s->fw, cpb,
                        (const unsigned long long *)(s->d_burst + B_SCATTER_BASE));

@@ -335,9 +335,11 @@ def test_device_driven_iterations_equal_host_driven_ones(name, best, monkeypatch
     text = open(golden("problems", name + ".txt")).read()
     model = solve_root(text)
     stats = {}
-    for mode, env in (("graph", {}), ("launches", {"CSGPU_SEARCH_GRAPH": "0"}), ("host", {"CSGPU_SEARCH_BURST": "0"})):
+    for mode, env in (("graph", {}), ("launches", {"CSGPU_SEARCH_GRAPH": "0"}), ("host", {"CSGPU_SEARCH_BURST": "0"}),
+                      ("one-workgroup", {"CSGPU_SEARCH_BURST_SPLIT": "0"})):
         monkeypatch.delenv("CSGPU_SEARCH_GRAPH", raising=False)
         monkeypatch.delenv("CSGPU_SEARCH_BURST", raising=False)
+        monkeypatch.delenv("CSGPU_SEARCH_BURST_SPLIT", raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         s = Search(model, 1 << 20, 1 << 16)
@@ -358,6 +360,8 @@ def test_device_driven_iterations_equal_host_driven_ones(name, best, monkeypatch
         assert int(truth[0]) == 1
         stats[mode] = st
     assert stats["graph"] == stats["launches"]  # the graph is only a way of launching
+    # a MIN / MAX iteration's bookkeeping by sixteen / thirty-two workgroups or by one: the same nodes in the same places
+    assert stats["graph"] == stats["one-workgroup"]
     # the host-driven loop learns of a new incumbent one iteration later, so it may expand a few more nodes
     assert stats["host"]["nodes"] >= stats["graph"]["nodes"]
 
@@ -576,3 +580,24 @@ def test_complete_nodes_of_a_ne_network_need_no_root_evaluation(monkeypatch):
                 truth = model.eval_root(torch.from_numpy(np.stack([row, row], 1)[None].astype(np.int32)).cuda())
                 assert int(truth[0]) == 1
         assert runs[0] == runs[1] and runs[0][0] > 0, runs
+
+
+@pytest.mark.gpu
+def test_split_bookkeeping_of_min_iterations_walks_the_same_tree(monkeypatch):
+    """Iterations of up to 1,024 parents (the default of MIN / MAX): branching + emitting by sixteen workgroups and
+    classification by thirty-two give, counter for counter, the search of the single-workgroup kernels."""
+    from csolve_amd import problems
+    from csolve_amd.solver import Search, solve_root
+    model = solve_root(problems.schedule(8, seed=3))
+    stats = {}
+    for mode in ("split", "one"):
+        monkeypatch.delenv("CSGPU_SEARCH_BURST_SPLIT", raising=False)
+        if mode == "one":
+            monkeypatch.setenv("CSGPU_SEARCH_BURST_SPLIT", "0")
+        s = Search(model, 1 << 21, 1 << 17)
+        s.put(model.root_state())
+        st = s.run(1 << 30)
+        assert st["done"] == 1
+        stats[mode] = st
+    assert stats["split"] == stats["one"]
+    assert stats["split"]["iterations"] > 10 and stats["split"]["nodes"] > 10000

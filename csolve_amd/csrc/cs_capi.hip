@@ -1612,6 +1612,9 @@ static int launch_eval_root(const csgpu_model *m, const csgpu_val *d_states, con
     /* grid-stride: enough workgroups to fill the machine, every wave keeps its share of the clause table */
     int64_t blocks = (count + CS_WAVES_PER_BLOCK - 1) / CS_WAVES_PER_BLOCK;
     if (blocks > (int64_t)m->n_cus * 16) blocks = (int64_t)m->n_cus * 16;
+    /* a count that stays on the device is the handful of complete children of a search iteration, `count` only their
+     * bound: one workgroup per CU (the waves stride over more), not thousands that start to find nothing to do */
+    if (d_count != NULL && blocks > (int64_t)m->n_cus) blocks = (int64_t)m->n_cus;
     const int per = (m->img->n_clauses + CS_WAVE - 1) / CS_WAVE;
 #define CS_LAUNCH_EVAL_T(CPL, TREE)                                                                \
   hipLaunchKernelGGL((cs_eval_root_waves<CPL, TREE>), dim3((unsigned)blocks), dim3(CS_BLOCK), row * CS_WAVES_PER_BLOCK, \

@@ -977,7 +977,8 @@ __global__ __launch_bounds__(1024) void cs_burst_emit(csgpu_node *__restrict__ n
 
 /* cs_classify_small by BURST_CLASS_WGS workgroups: cs_burst_count leaves each workgroup's class counts (its share is
  * children / BURST_CLASS_WGS consecutive children), cs_burst_assign adds up its predecessors' and writes the lists in
- * child order; its workgroup 0 moves the pool top and the totals. */
+ * child order, copies ITS survivors into the pool (no cs_scatter launch); its workgroup 0 moves the pool top and the
+ * totals. */
 __device__ __forceinline__ void cs_burst_share(int children, int g, int *beg, int *end) {
   const int chunk = (children + BURST_CLASS_WGS - 1) / BURST_CLASS_WGS;
   const long long b = (long long)g * chunk, e = b + chunk;
@@ -1021,13 +1022,17 @@ __global__ __launch_bounds__(1024) void cs_burst_assign(const csgpu_result *__re
                                                         unsigned long long *__restrict__ burst,
                                                         const int *__restrict__ wg_surv, const int *__restrict__ wg_comp,
                                                         const int *__restrict__ wg_cuts, const int *__restrict__ wg_props,
-                                                        const int *__restrict__ wg_revs) {
+                                                        const int *__restrict__ wg_revs,
+                                                        const cs_val *__restrict__ child_states, cs_val *__restrict__ pool,
+                                                        int n, const unsigned long long *__restrict__ child_forb,
+                                                        unsigned long long *__restrict__ pool_forb, int fw) {
   __shared__ long long s_part[16];
   const int g = (int)blockIdx.x;
   int beg, end;
   cs_burst_share((int)counters[C_TOTAL_CHILDREN], g, &beg, &end);
   long long carry = 0; /* survivors | complete children << 32 before this workgroup's share */
   for (int h = 0; h < g; h++) carry += (long long)wg_surv[h] | ((long long)wg_comp[h] << 32);
+  const int first_surv = (int)(carry & 0xffffffffll);
   for (int base = beg; base < end; base += 1024) {
     const int i = base + (int)threadIdx.x;
     const int status = i < end ? res[i].status : -2;
@@ -1037,6 +1042,36 @@ __global__ __launch_bounds__(1024) void cs_burst_assign(const csgpu_result *__re
     if (status > 0) surv_list[ex & 0xffffffffll] = i;
     if (status == 0) complete_list[ex >> 32] = i;
     carry += total;
+  }
+  /* cs_scatter for this workgroup's survivors: rows first_surv .. of the new pool top (the rows of the iteration's
+   * parents, B_D_FIRST, are the first to be overwritten: LIFO), walked flat so that small models fill the lanes */
+  const int here = (int)(carry & 0xffffffffll) - first_surv;
+  if (here > 0) { /* uniform */
+    __syncthreads(); /* this workgroup's part of surv_list is written */
+    const long long row0 = (long long)burst[B_D_FIRST] + first_surv;
+    const int *src = surv_list + first_surv;
+    {
+      const int total = here * n;
+      int c = (int)threadIdx.x / n, v = (int)threadIdx.x - c * n;
+      const int dc = 1024 / n, dv = 1024 - dc * n;
+      cs_val *dst = pool + (size_t)row0 * n;
+      for (int e = (int)threadIdx.x; e < total; e += 1024) {
+        dst[e] = child_states[(size_t)src[c] * n + v];
+        c += dc; v += dv;
+        if (v >= n) { v -= n; c++; }
+      }
+    }
+    if (fw > 0) {
+      const int nf = n * fw, total = here * nf;
+      int c = (int)threadIdx.x / nf, k = (int)threadIdx.x - c * nf;
+      const int dc = 1024 / nf, dk = 1024 - dc * nf;
+      unsigned long long *dst = pool_forb + (size_t)row0 * nf;
+      for (int e = (int)threadIdx.x; e < total; e += 1024) {
+        dst[e] = child_forb[(size_t)src[c] * nf + k];
+        c += dc; k += dk;
+        if (k >= nf) { k -= nf; c++; }
+      }
+    }
   }
   if (g == 0 && threadIdx.x == 0) {
     long long surv = 0, comp = 0, cuts = 0, props = 0, revs = 0;
@@ -1971,13 +2006,15 @@ static int enqueue_burst(csgpu_search *s, hipStream_t st) {
       hipLaunchKernelGGL(cs_burst_assign, dim3(BURST_CLASS_WGS), dim3(1024), 0, st, (const csgpu_result *)s->d_results,
                          s->d_dest, s->d_complete_list, s->d_counters, s->d_burst, (const int *)s->d_block_surv,
                          (const int *)s->d_block_comp, (const int *)s->d_block_cuts, (const int *)s->d_block_props,
-                         (const int *)s->d_block_revs);
-    } else
+                         (const int *)s->d_block_revs, (const cs_val *)s->d_child_states, s->pool, n,
+                         (const unsigned long long *)s->d_child_forb, s->pool_forb, s->fw);
+    } else {
       hipLaunchKernelGGL(cs_classify_small, dim3(1), dim3(1024), 0, st, s->d_results, s->d_dest, s->d_complete_list,
                          s->d_counters, s->d_burst);
-    hipLaunchKernelGGL(cs_scatter, dim3((unsigned)((bound + cpb - 1) / cpb)), dim3(SB), 0, st, s->d_child_states, s->d_dest,
-                       s->d_counters, 0ll, n, s->pool, s->d_child_forb, s->pool_forb, s->fw, cpb,
-                       (const unsigned long long *)(s->d_burst + B_SCATTER_BASE));
+      hipLaunchKernelGGL(cs_scatter, dim3((unsigned)((bound + cpb - 1) / cpb)), dim3(SB), 0, st, s->d_child_states, s->d_dest,
+                         s->d_counters, 0ll, n, s->pool, s->d_child_forb, s->pool_forb, s->fw, cpb,
+                         (const unsigned long long *)(s->d_burst + B_SCATTER_BASE));
+    }
     rc = csgpu_internal_eval_list(s->m, (const csgpu_val *)s->d_child_states, s->d_complete_list,
                                   (const uint64_t *)(s->d_counters + C_COMPLETE), bound, s->d_truth, st);
     if (rc != CSGPU_OK) return rc;

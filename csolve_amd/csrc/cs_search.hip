@@ -129,6 +129,7 @@ struct csgpu_search {
   int burst_off;       /* CSGPU_SEARCH_BURST=0: every iteration driven from the host */
   int eval_always;     /* CSGPU_SEARCH_EVAL=1: complete children of pure != networks are evaluated all the same (tests) */
   int graph_off;       /* CSGPU_SEARCH_GRAPH=0: the launches of a burst enqueued one by one */
+  int burst_no_eval;   /* device-driven iterations launch no root evaluation: see enqueue_burst */
   int burst_split;     /* MIN / MAX: expansion and classification of a device-driven iteration by several workgroups
                         * (CSGPU_SEARCH_BURST_SPLIT=0: by one, as ANY) */
 };
@@ -682,7 +683,7 @@ __device__ __forceinline__ void cs_accept_block(const cs_val *__restrict__ child
   int cnt = 0;
   if (t < 256)
     for (int i = t; i < count; i += 256) {
-      if (truth[i] != 1) continue;
+      if (truth != nullptr && truth[i] != 1) continue; /* truth == NULL: every complete child is a solution */
       cnt++;
       long long val = 0;
       if (opt) {
@@ -1421,6 +1422,8 @@ extern "C" int csgpu_search_create(const csgpu_model *m, int64_t pool_capacity, 
     s->eval_always = ev != NULL && ev[0] == '1';
     e = getenv("CSGPU_SEARCH_GRAPH");
     s->graph_off = e != NULL && e[0] == '0';
+    int64_t info[8];
+    s->burst_no_eval = !s->eval_always && csgpu_model_device_info(m, info) == CSGPU_OK && info[2] == 0;
   }
   *out = s;
   return CSGPU_OK;
@@ -1970,12 +1973,18 @@ static int enqueue_burst(csgpu_search *s, hipStream_t st) {
   while (cpb > 4 && bound / cpb < 2048) cpb >>= 1;
   /* ANY dives with few parents and must see the accept before it decides: one workgroup */
   const int split = s->burst_split && s->objective != CS_OBJ_ANY;
+  /* Without expression-tree clauses a complete consistent child IS a solution, and evaluating the root (eval_wand over
+   * every clause, eval.c:233-255) can only say "true": every clause is a binary relation or a two-literal disjunction
+   * whose revision on valued operands fails exactly when it is violated, and each was revised after the last of its
+   * variables became a value (in this node or in the ancestor that valued it; the root's own valued clauses by the root
+   * phase).  The launch that would say so is left out (CSGPU_SEARCH_EVAL=1 keeps it: tests compare the two). */
+  const int *truth = s->burst_no_eval ? (const int *)NULL : (const int *)s->d_truth;
   for (int it = 0; it < BURST_ITERATIONS; it++) {
     if (split) {
       hipLaunchKernelGGL(cs_burst_branch, dim3(BURST_WGS), dim3(1024), 0, st, s->pool, n, s->d_counters, s->d_burst,
                          s->objective, (long long)s->max_width, (long long)s->cap, room_limit, s->holes, s->d_choice,
                          s->d_block_sum, s->d_block_skip, (const cs_val *)s->d_child_states,
-                         (const int *)s->d_complete_list, (const int *)s->d_truth, s->obj_var, s->d_solutions,
+                         (const int *)s->d_complete_list, truth, s->obj_var, s->d_solutions,
                          (long long)s->max_solutions, s->d_best_solution, s->d_best);
       hipLaunchKernelGGL(cs_burst_emit, dim3(BURST_WGS), dim3(1024), 0, st, s->d_nodes, s->d_counters, s->d_burst,
                          s->objective, (const cs_choice *)s->d_choice, (const int *)s->d_block_sum,
@@ -1983,7 +1992,7 @@ static int enqueue_burst(csgpu_search *s, hipStream_t st) {
     } else
       hipLaunchKernelGGL(cs_expand_burst, dim3(1), dim3(1024), 0, st, s->pool, n, s->d_nodes, s->d_counters, s->d_burst,
                          s->objective, (long long)s->max_width, (long long)s->cap, room_limit, s->holes,
-                         (const cs_val *)s->d_child_states, (const int *)s->d_complete_list, (const int *)s->d_truth,
+                         (const cs_val *)s->d_child_states, (const int *)s->d_complete_list, truth,
                          s->obj_var, s->d_solutions, (long long)s->max_solutions, s->d_best_solution, s->d_best);
     int rc;
     if (s->fw > 0)
@@ -2015,12 +2024,14 @@ static int enqueue_burst(csgpu_search *s, hipStream_t st) {
                          s->d_counters, 0ll, n, s->pool, s->d_child_forb, s->pool_forb, s->fw, cpb,
                          (const unsigned long long *)(s->d_burst + B_SCATTER_BASE));
     }
-    rc = csgpu_internal_eval_list(s->m, (const csgpu_val *)s->d_child_states, s->d_complete_list,
-                                  (const uint64_t *)(s->d_counters + C_COMPLETE), bound, s->d_truth, st);
-    if (rc != CSGPU_OK) return rc;
+    if (truth != NULL) {
+      rc = csgpu_internal_eval_list(s->m, (const csgpu_val *)s->d_child_states, s->d_complete_list,
+                                    (const uint64_t *)(s->d_counters + C_COMPLETE), bound, s->d_truth, st);
+      if (rc != CSGPU_OK) return rc;
+    }
   }
   /* the last iteration's accept (the others ran at the head of the following expansion) */
-  hipLaunchKernelGGL(cs_accept_burst, dim3(1), dim3(256), 0, st, s->d_child_states, s->d_complete_list, s->d_truth, n,
+  hipLaunchKernelGGL(cs_accept_burst, dim3(1), dim3(256), 0, st, s->d_child_states, s->d_complete_list, truth, n,
                      s->objective, s->obj_var, s->d_counters, s->d_burst, s->d_solutions, (long long)s->max_solutions,
                      s->d_best_solution, s->d_best);
   HIP_OK(hipGetLastError());

@@ -336,10 +336,11 @@ def test_device_driven_iterations_equal_host_driven_ones(name, best, monkeypatch
     model = solve_root(text)
     stats = {}
     for mode, env in (("graph", {}), ("launches", {"CSGPU_SEARCH_GRAPH": "0"}), ("host", {"CSGPU_SEARCH_BURST": "0"}),
-                      ("one-workgroup", {"CSGPU_SEARCH_BURST_SPLIT": "0"})):
+                      ("one-workgroup", {"CSGPU_SEARCH_BURST_SPLIT": "0"}), ("evaluated", {"CSGPU_SEARCH_EVAL": "1"})):
         monkeypatch.delenv("CSGPU_SEARCH_GRAPH", raising=False)
         monkeypatch.delenv("CSGPU_SEARCH_BURST", raising=False)
         monkeypatch.delenv("CSGPU_SEARCH_BURST_SPLIT", raising=False)
+        monkeypatch.delenv("CSGPU_SEARCH_EVAL", raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         s = Search(model, 1 << 20, 1 << 16)
@@ -362,6 +363,9 @@ def test_device_driven_iterations_equal_host_driven_ones(name, best, monkeypatch
     assert stats["graph"] == stats["launches"]  # the graph is only a way of launching
     # a MIN / MAX iteration's bookkeeping by sixteen / thirty-two workgroups or by one: the same nodes in the same places
     assert stats["graph"] == stats["one-workgroup"]
+    # models without expression-tree clauses launch no root evaluation for their complete children (it can only say
+    # "true"); CSGPU_SEARCH_EVAL=1 evaluates them all the same: not one is rejected, the search is the same search
+    assert stats["graph"] == stats["evaluated"]
     # the host-driven loop learns of a new incumbent one iteration later, so it may expand a few more nodes
     assert stats["host"]["nodes"] >= stats["graph"]["nodes"]
 
@@ -590,14 +594,17 @@ def test_split_bookkeeping_of_min_iterations_walks_the_same_tree(monkeypatch):
     from csolve_amd.solver import Search, solve_root
     model = solve_root(problems.schedule(8, seed=3))
     stats = {}
-    for mode in ("split", "one"):
+    for mode in ("split", "one", "evaluated"):
         monkeypatch.delenv("CSGPU_SEARCH_BURST_SPLIT", raising=False)
+        monkeypatch.delenv("CSGPU_SEARCH_EVAL", raising=False)
         if mode == "one":
             monkeypatch.setenv("CSGPU_SEARCH_BURST_SPLIT", "0")
+        if mode == "evaluated":  # the root evaluation of complete children, left out for models without tree clauses
+            monkeypatch.setenv("CSGPU_SEARCH_EVAL", "1")
         s = Search(model, 1 << 21, 1 << 17)
         s.put(model.root_state())
         st = s.run(1 << 30)
         assert st["done"] == 1
         stats[mode] = st
-    assert stats["split"] == stats["one"]
+    assert stats["split"] == stats["one"] == stats["evaluated"]
     assert stats["split"]["iterations"] > 10 and stats["split"]["nodes"] > 10000

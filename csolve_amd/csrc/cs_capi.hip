@@ -797,7 +797,11 @@ extern "C" int csgpu_model_finalize(csgpu_model *m) {
     const size_t adj_bytes = (((size_t)m->img->n_adj * (size_t)m->img->packed_width) + 15) & ~(size_t)15;
     const size_t lds_slice = ((size_t)h->n_vars * sizeof(cs_val) + (2 * (size_t)m->tab.n_words + 1) * sizeof(unsigned) + 15) & ~(size_t)15;
     m->lds_adj_global = 0;
-    for (int waves = 16; waves >= 4; waves >>= 1) {
+    /* as many waves as fit next to the lists (not only 16, 8 or 4: the 25x25 sudoku's lists leave room for fifteen
+     * slices, and with eight its nodes' chains of dependent steps had two waves per SIMD to hide behind) */
+    int waves_max = 16;
+    { const char *e = getenv("CSGPU_K2_WAVES"); if (e != NULL && atoi(e) >= 4 && atoi(e) <= 16) waves_max = atoi(e); } /* measurement override */
+    for (int waves = waves_max; waves >= 4; waves--) {
       const size_t need = off_bytes + adj_bytes + (size_t)waves * lds_slice;
       if (need <= 160u * 1024u) {
         m->lds_waves = waves;

@@ -79,6 +79,7 @@ def load_library():
     L.csgpu_model_root_propagate.argtypes = [vp, C.POINTER(i32)]
     L.csgpu_model_finalize.argtypes = [vp]
     L.csgpu_model_normalize.argtypes = [vp]
+    L.csgpu_model_specialize.argtypes = [vp, vp, C.POINTER(vp)]
     L.csgpu_model_build_tables.argtypes = [vp]
     L.csgpu_model_eval_clauses_host.argtypes = [vp, vp]
     L.csgpu_model_set_kernel.argtypes = [vp, C.c_int]

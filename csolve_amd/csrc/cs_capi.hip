@@ -477,6 +477,28 @@ extern "C" int csgpu_model_normalize(csgpu_model *m) {
   return CSGPU_OK;
 }
 
+/* the model rewritten for the subtree below `state` -- a copy whose root domains are `state`, ready for
+ * csgpu_model_normalize (which folds what the prefix has decided: normalize.c:67-75 replaces every subtree that now
+ * evaluates to a value by that value, neutral elements and satisfied clauses drop out) and csgpu_model_finalize (which
+ * leaves clauses that are true on the whole of `state` out of the device tables).  The reference does this inside the
+ * search, clause by clause (normalize + patch at the end of propagate_clauses, propagate.c:521-535, undone on
+ * backtracking); here it is a host-side pre-pass per subtree, as the survey puts it. */
+extern "C" int csgpu_model_specialize(const csgpu_model *m, const csgpu_val *state, csgpu_model **out) {
+  if (m == NULL || state == NULL || out == NULL) return set_err(CSGPU_E_ARG, "null argument");
+  const cs_model *h = m->host;
+  if (h->root < 0) return set_err(CSGPU_E_STATE, "model has no root");
+  for (int32_t v = 0; v < h->n_vars; v++) {
+    if (state[v].lo > state[v].hi) return set_err(CSGPU_E_ARG, "variable %d: empty interval", v);
+    if (state[v].lo < h->dom[v].lo || state[v].hi > h->dom[v].hi)
+      return set_err(CSGPU_E_ARG, "variable %d: [%d, %d] is not inside the model's [%d, %d]", v, state[v].lo, state[v].hi,
+                     h->dom[v].lo, h->dom[v].hi);
+  }
+  cs_model *copy = cs_model_clone(h);
+  if (copy == NULL) return set_err(CSGPU_E_LIMIT, "out of memory");
+  memcpy(copy->dom, state, (size_t)h->n_vars * sizeof(cs_val));
+  return wrap_model(copy, 0, out);
+}
+
 extern "C" int csgpu_model_add_conflict(csgpu_model *m, int32_t count, const int32_t *vars, const int32_t *values) {
   if (m == NULL || count < 1 || vars == NULL || values == NULL) return set_err(CSGPU_E_ARG, "bad argument");
   cs_model *h = m->host;

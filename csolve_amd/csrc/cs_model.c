@@ -47,6 +47,51 @@ void cs_model_free(cs_model *m) {
   free(m);
 }
 
+/* a deep copy WITHOUT the clause index (cs_model_index rebuilds it): the trees, domains, names and weights of `src`,
+ * for a model that is to be rewritten on its own (csgpu_model_specialize) */
+static void *copy_of(const void *p, size_t bytes, size_t alloc_bytes) {
+  void *q = xrealloc(NULL, alloc_bytes > bytes ? alloc_bytes : (bytes ? bytes : 1));
+  if (bytes && p != NULL) memcpy(q, p, bytes);
+  return q;
+}
+
+cs_model *cs_model_clone(const cs_model *src) {
+  cs_model *m = cs_model_new();
+  const int32_t nv = src->n_vars;
+  m->n_vars = nv;
+  m->cap_vars = nv ? nv : 1;
+  m->dom = (cs_val *)xrealloc(NULL, (size_t)m->cap_vars * sizeof(cs_val));
+  m->prio = (int64_t *)xrealloc(NULL, (size_t)m->cap_vars * sizeof(int64_t));
+  m->var_node = (int32_t *)xrealloc(NULL, (size_t)m->cap_vars * sizeof(int32_t));
+  m->names = (char **)calloc((size_t)m->cap_vars, sizeof(char *));
+  memcpy(m->dom, src->dom, (size_t)nv * sizeof(cs_val));
+  memcpy(m->prio, src->prio, (size_t)nv * sizeof(int64_t));
+  memcpy(m->var_node, src->var_node, (size_t)nv * sizeof(int32_t));
+  for (int32_t v = 0; v < nv; v++) m->names[v] = (char *)copy_of(src->names[v], strlen(src->names[v]) + 1, 0);
+  m->n_nodes = src->n_nodes;
+  m->cap_nodes = src->n_nodes > 4 ? src->n_nodes : 4;
+  free(m->nodes);
+  m->nodes = (cs_node *)copy_of(src->nodes, (size_t)src->n_nodes * sizeof(cs_node), (size_t)m->cap_nodes * sizeof(cs_node));
+  m->n_kids = src->n_kids;
+  m->cap_kids = src->n_kids > 4 ? src->n_kids : 4;
+  free(m->kids);
+  m->kids = (int32_t *)copy_of(src->kids, (size_t)src->n_kids * sizeof(int32_t), (size_t)m->cap_kids * sizeof(int32_t));
+  m->root = src->root;
+  m->n_top = src->n_top;
+  m->cap_top = src->n_top > 4 ? src->n_top : 4;
+  free(m->top);
+  m->top = (int32_t *)copy_of(src->top, (size_t)src->n_top * sizeof(int32_t), (size_t)m->cap_top * sizeof(int32_t));
+  m->objective = src->objective;
+  m->obj_var = src->obj_var;
+  m->weights_on = src->weights_on;
+  if (src->name_tab != NULL && src->name_cap > 0) {
+    free(m->name_tab);
+    m->name_cap = src->name_cap;
+    m->name_tab = (int32_t *)copy_of(src->name_tab, (size_t)src->name_cap * sizeof(int32_t), 0);
+  }
+  return m;
+}
+
 /* ---- name table ---------------------------------------------------------- */
 
 static uint32_t name_hash(const char *s) {

@@ -67,6 +67,8 @@ typedef struct cs_model {
 
 cs_model *cs_model_new(void);
 void cs_model_free(cs_model *m);
+/* deep copy of trees, domains, names and weights; the clause index is left out (cs_model_index rebuilds it) */
+cs_model *cs_model_clone(const cs_model *src);
 
 /* low-level construction (used by the builder, the loaders and the drop-in shim) */
 int32_t cs_model_add_var(cs_model *m, const char *name, cs_val dom);

@@ -122,6 +122,25 @@ class Model:
         check(load_library().csgpu_model_normalize(self._h))
         return self
 
+    def specialize(self, state, build_only: bool = False) -> "Model":
+        """the model rewritten for the subtree below `state` ([n_vars][2] intervals inside the root
+        domains): a copy with `state` as root domains, normalised (what the prefix has decided is folded away,
+        normalize.c:67-316), propagated and finalized (entailed clauses leave the device tables).  Same results as
+        this model for every state inside `state`; shorter clause lists.  build_only: host tables only (no GPU)."""
+        state = np.ascontiguousarray(np.asarray(state.cpu() if hasattr(state, "cpu") else state), dtype=np.int32)
+        state = state.reshape(-1, self.n_vars, 2)
+        assert state.shape[0] == 1, "one state (a common prefix), not a batch"
+        state = np.ascontiguousarray(state[0])
+        h = C.c_void_p()
+        check(load_library().csgpu_model_specialize(self._h, state.ctypes.data, C.byref(h)))
+        m = Model(h)
+        m.normalize()
+        if build_only:
+            return m.build_tables()
+        if m.root_propagate() < 0:
+            raise ValueError("INFEASIBLE PROBLEM")
+        return m.finalize()
+
     def add_conflict(self, elems):
         """a learnt conflict clause "not all of var == value" for elems = [(var, value)] (csgpu_model_add_conflict)"""
         vs = np.ascontiguousarray([e[0] for e in elems], dtype=np.int32)

@@ -112,6 +112,13 @@ int csgpu_model_root_propagate_limit(csgpu_model *m, int64_t limit, int32_t *sta
  * src/normalize.c:305-316, parser.y:66): a host-side rewrite of the trees (constant folding,
  * neutral elements, constants moved across `<`, double negation, De Morgan); no domain changes. */
 int csgpu_model_normalize(csgpu_model *m);
+/* SURVEY 8f-1 (the normaliser as a pre-pass that specialises the tables per subtree prefix): a new, unfinalized model
+ * for the subtree below `state` (one interval per variable, inside the model's root domains; normally a consistent
+ * state a search has reached): the same trees with `state` as root domains.  csgpu_model_normalize on it folds what the
+ * prefix has decided (normalize.c:67-316), csgpu_model_root_propagate re-establishes the fixpoint, csgpu_model_finalize
+ * leaves entailed clauses out of the device tables: shorter clause lists, the same results for every state inside
+ * `state` (normalisation never changes results, only cost).  The new model is independent of `m`. */
+int csgpu_model_specialize(const csgpu_model *m, const csgpu_val *state, csgpu_model **out);
 /* A learnt conflict clause (struct confl_t, csolve.h:98-128; conflict_create, conflict.c:319-361): "not all of
  * vars[i] == values[i]".  It is evaluated like eval_confl (eval.c:258-277) and propagated like propagate_confl
  * (propagate.c:395-471: when every element but one has its conflict value, that value is shaved off the bound of

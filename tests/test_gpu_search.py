@@ -608,3 +608,57 @@ def test_split_bookkeeping_of_min_iterations_walks_the_same_tree(monkeypatch):
         stats[mode] = st
     assert stats["split"] == stats["one"] == stats["evaluated"]
     assert stats["split"]["iterations"] > 10 and stats["split"]["nodes"] > 10000
+
+
+def _prefix_state(model, steps, seed):
+    """a consistent state `steps` assignments below the root: seeded random variable, lowest value, propagated"""
+    rng = np.random.default_rng(seed)
+    state = model.root_state()
+    for _ in range(steps):
+        dom = state[0].cpu().numpy()
+        open_vars = [v for v in range(model.n_vars) if dom[v, 0] != dom[v, 1] and v != model.objective_var]
+        if not open_vars:
+            break
+        v = int(rng.choice(open_vars))
+        for value in range(int(dom[v, 0]), int(dom[v, 1]) + 1):
+            nodes = torch.tensor([[v, value, value, 0]], dtype=torch.int32, device="cuda")
+            out, res = model.propagate(state, nodes)
+            if int(res[0, 0]) >= 0:
+                state = out[:1].contiguous()
+                break
+    return state
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which,steps", [("schedule8", 3), ("schedule8", 6), ("ref_wcet", 4), ("queens10", 2), ("sudoku9", 5)])
+def test_a_model_specialised_for_a_subtree_gives_the_subtrees_results(which, steps):
+    """csgpu_model_specialize + normalize + finalize rewrite the tables for the subtree below a prefix
+    state (what the prefix decided is folded, entailed clauses leave the lists).  Results-neutral: the search below
+    the prefix finds the same solutions / the same optimum with either model, over the same tree."""
+    from csolve_amd import problems
+    from csolve_amd.solver import Search, solve_root
+    text = {"schedule8": lambda: problems.schedule(8, seed=3), "queens10": lambda: problems.queens(10, "ALL"),
+            "ref_wcet": lambda: open(golden("problems", "ref_wcet.txt")).read(),
+            "sudoku9": lambda: problems.sudoku(3, 0.3, 2).replace("ANY", "ALL", 1)}[which]()
+    model = solve_root(text)
+    prefix = _prefix_state(model, steps, seed=11)
+    special = model.specialize(prefix)
+    info, info_s = model.device_info(), special.device_info()
+    # nothing is added, and what the prefix decided is gone from the lists
+    assert info_s["adjacency_entries"] <= info["adjacency_entries"]
+    runs = []
+    for m in (model, special):
+        s = Search(m, 1 << 19, 1 << 15)
+        s.put(prefix)
+        st = s.run(1 << 40)
+        assert st["done"] == 1
+        sols = sorted(map(tuple, s.solutions(4096).tolist())) if m.objective == 1 else None
+        runs.append((st, sols, s.best_solution()))
+    (a, sa, ba), (b, sb, bb) = runs
+    assert a["solutions"] == b["solutions"] and a["best"] == b["best"] and sa == sb
+    if model.objective in (2, 3) and ba is not None:
+        assert bb is not None and ba[model.objective_var] == bb[model.objective_var]
+    if model.objective == 1:  # ALL: the same tree, node for node
+        assert (a["nodes"], a["cuts"]) == (b["nodes"], b["cuts"])
+    print(which, steps, "adjacency", info["adjacency_entries"], "->", info_s["adjacency_entries"],
+          "clauses", model.n_clauses, "->", special.n_clauses, "nodes", a["nodes"], b["nodes"])

@@ -362,3 +362,29 @@ def test_the_engines_branching_key_orders_variables_like_strategy_var_cmp():
         assert sign == c["sign"], (c, ka, kb)
     # ties go to the lower index
     assert L.csgpu_branch_key(1, 0, _lib.Val(1, 5), 0, 3) < L.csgpu_branch_key(1, 0, _lib.Val(1, 5), 0, 4)
+
+
+def test_a_specialised_model_drops_what_its_prefix_decides():
+    """SURVEY 8f-1 on the host: csgpu_model_specialize copies the model with a subtree's prefix state as root domains;
+    the normaliser then folds the valued variables into their clauses (normalize.c:67-75) and the table builder leaves
+    constant clauses out of the lists.  (That the search below the prefix gives the same results with either model is
+    the GPU suite's test_a_model_specialised_for_a_subtree_gives_the_subtrees_results.)"""
+    from csolve_amd._lib import CsolveError
+    from csolve_amd.solver import Model
+    m = Model.from_dump(golden("models", "schedule6_s1.model"))
+    base = m.build_tables().device_info()
+    dom = m.domains()
+    names = m.var_names()
+    prefix = dom.copy()
+    starts = [v for v, name in enumerate(names) if name.endswith("_start")]
+    for v in starts[:3]:  # three start times decided: every disjunction between two of them is decided with them
+        prefix[v, 1] = prefix[v, 0]
+    s = m.specialize(prefix, build_only=True)
+    info = s.device_info()
+    assert s.n_vars == m.n_vars and info["adjacency_entries"] < base["adjacency_entries"]
+    assert (s.domains() == prefix).all() and (m.domains() == dom).all()  # the copy is independent of the model
+    # a state outside the model's root domains is refused
+    bad = dom.copy()
+    bad[starts[0], 1] += 1
+    with pytest.raises(CsolveError):
+        m.specialize(bad, build_only=True)

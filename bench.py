@@ -109,6 +109,7 @@ from csolve_amd import problems  # noqa: E402
 from csolve_amd.solver import solve_root  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+STREAMING_CEILING_GBS = 5900.0  # measured copy-kernel ceiling of this part for row-shaped traffic
 
 
 def measured_traffic(kernel_name, workload_key, instances):
@@ -610,6 +611,8 @@ def main():
                    "revisions_per_node": revs_all / nodes_all},
         "roofline": roofline_record(head, workload_key, B),
     }
+    if rank == 0:
+        out["roofline"]["streaming_ceiling"]["device_copy_gbps_this_run"] = device_copy_gbps()
     if not legs["headline_only"]:
         out["legs"] = {k: leg_summary(v) for k, v in legs["legs"].items()}
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -753,6 +756,29 @@ def run_propagation_legs(args, text, instances, seed, dist=None, headline_only=F
             "headline_only": headline_only}
 
 
+def device_copy_gbps(bytes_each=1 << 30, reps=5):
+    """the box's measured copy bandwidth next to the nominal peak -- a device-to-device copy of 1 GiB
+    (read + write counted), best of `reps`, outside every timed region."""
+    try:
+        src = torch.empty(bytes_each, dtype=torch.uint8, device="cuda")
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        best = None
+        for _ in range(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            dst.copy_(src)
+            b.record()
+            torch.cuda.synchronize()
+            ms = a.elapsed_time(b)
+            best = ms if best is None or ms < best else best
+        del src, dst
+        torch.cuda.empty_cache()
+        return 2 * bytes_each / (best * 1e-3) / 1e9
+    except Exception:  # not enough memory left: the figure is an annotation, not a result
+        return None
+
+
 def roofline_record(leg, workload_key, B):
     """HBM roofline of one leg.  `achieved` / `frac` are on the bytes a node instance NEEDS: the parent state in
     (`struct val_t` per variable: 8 n), the 16-byte node record, the 16-byte result, and the state out (8 n) for the
@@ -778,7 +804,12 @@ def roofline_record(leg, workload_key, B):
             "layout_frac": leg["layout_bytes"] / t / 1e9 / HBM_PEAK_GBS,
             "traffic_over_necessary": None if traffic is None else traffic / needed,
             "output_rows_stored": leg["stored_rows"],
-            "survey_8d_formula_gbps": survey_bytes / t / 1e9}
+            "survey_8d_formula_gbps": survey_bytes / t / 1e9,
+            # what a kernel that only moves rows of this shape reaches on this part (tools/hbm_ceiling.hip: rows in, rows
+            # out, no computation; 5.4-6.1 TB/s depending on size, hipMemcpyAsync D2D 5.1-5.3): `peak` stays the nominal
+            # 8 TB/s, this says how much of the gap is the memory system's
+            "streaming_ceiling": {"gbps": STREAMING_CEILING_GBS, "frac_of_it": needed / t / 1e9 / STREAMING_CEILING_GBS,
+                                  "source": "profiles/r01_h_hbm_streaming_ceiling.txt (tools/hbm_ceiling.hip, 2-8 GB per launch)"}}
 
 
 def leg_summary(leg):

@@ -62,8 +62,9 @@ enum { B_TOP = 0, B_BUDGET, B_LIMIT, B_LIMIT_MAX, B_ITER_BASE, B_ITERS, B_NODES,
 #define BURST_ITERATIONS 16
 /* a MIN / MAX iteration's bookkeeping is spread over this many workgroups (one workgroup is bound by what ONE CU
  * reads, ~25 GB/s: 1,024 parent rows took it 24 us, 10,000 results 18 us) */
-#define BURST_WGS 16
-#define BURST_PPW (SMALL_PARENTS / BURST_WGS) /* parents per workgroup: sixteen lanes each, one pass */
+#define BURST_PPW 64        /* parents per workgroup: sixteen lanes each, one pass of 1,024 threads */
+#define BURST_WGS_MAX 64    /* one wave adds up the workgroups' child counts: at most 4,096 parents per iteration */
+#define BURST_PARENTS_MAX (BURST_PPW * BURST_WGS_MAX)
 #define BURST_CLASS_WGS 32
 
 struct csgpu_search {
@@ -865,7 +866,7 @@ __global__ __launch_bounds__(1024) void cs_expand_burst(const cs_val *__restrict
     cs_emit_seg<16>(s_choice[p], first_row + p, s_off[p], nodes, low_values_last, scramble, (int)threadIdx.x & 15);
 }
 
-/* ---- the same iteration by BURST_WGS workgroups (MIN / MAX, whose iterations take up to 1,024 parents) ----
+/* ---- the same iteration by up to BURST_WGS_MAX workgroups (MIN / MAX, whose iterations take 1,024 parents and more) ----
  * cs_burst_branch: workgroup g chooses for parents [64 g, 64 g + 64) and leaves their child counts' sum; workgroup 0
  * also runs the previous iteration's accept and publishes the head.  Nothing any workgroup READS to decide the head
  * is written here (the accept touches the incumbent, the solution counters and B_IMPROVED only), so all of them
@@ -930,6 +931,7 @@ __global__ __launch_bounds__(1024) void cs_burst_emit(csgpu_node *__restrict__ n
                                                       unsigned long long *__restrict__ burst, int objective,
                                                       const cs_choice *__restrict__ choice,
                                                       const int *__restrict__ wg_sum, const int *__restrict__ wg_skip) {
+  const int wgs = (int)gridDim.x; /* <= BURST_WGS_MAX = the lanes of the wave that adds them up */
   __shared__ cs_choice s_choice[BURST_PPW];
   __shared__ int s_off[BURST_PPW];
   const int g = (int)blockIdx.x;
@@ -945,7 +947,7 @@ __global__ __launch_bounds__(1024) void cs_burst_emit(csgpu_node *__restrict__ n
     s_choice[t] = c;
     /* the children before this workgroup's parents, then before this parent */
     int before = t < g ? wg_sum[t] : 0;
-    int all = t < BURST_WGS ? wg_sum[t] : 0, all_skip = t < BURST_WGS ? wg_skip[t] : 0;
+    int all = t < wgs ? wg_sum[t] : 0, all_skip = t < wgs ? wg_skip[t] : 0;
     int incl = c.count;
     for (int d = 1; d < 64; d <<= 1) {
       const int up = __shfl_up(incl, d);
@@ -1305,11 +1307,16 @@ extern "C" int csgpu_search_create(const csgpu_model *m, int64_t pool_capacity, 
   s->parents_max = s->parents_limit;
   if (csgpu_model_objective(m) == CS_OBJ_MIN || csgpu_model_objective(m) == CS_OBJ_MAX) { /* ANY stays depth-first */
     /* parents of a device-driven MIN / MAX iteration once the pool holds a backlog (tuning: CSGPU_SEARCH_PARENTS_MAX) */
-    int64_t want = 1024; /* schedule-12 MIN: 9.7 s with 256, 7.3 s with 512, 6.3 s with 1,024 (more nodes, fewer and fuller iterations) */
+    /* schedule-12 MIN: 9.7 s with 256, 7.3 s with 512, 6.3 s with 1,024 (round 3, single-workgroup bookkeeping); with the
+     * bookkeeping over many workgroups 3.84 s with 1,024 and 3.37 s with 2,048 (10 % more nodes in 20 % fewer, fuller
+     * iterations; 4,096 changes nothing: a twentieth of the pool is rarely that many) */
+    int64_t want = 2048;
     {
       const char *e = getenv("CSGPU_SEARCH_PARENTS_MAX");
       if (e != NULL && atoll(e) > 0) want = atoll(e);
-      if (want > SMALL_PARENTS) want = SMALL_PARENTS;
+      const char *es = getenv("CSGPU_SEARCH_BURST_SPLIT");
+      const int64_t most = es != NULL && es[0] == '0' ? SMALL_PARENTS : BURST_PARENTS_MAX; /* what one workgroup scans */
+      if (want > most) want = most;
     }
     s->parents_max = want < s->max_parents ? want : s->max_parents;
     if (s->parents_max < s->parents_limit) s->parents_max = s->parents_limit;
@@ -1957,7 +1964,8 @@ static int one_iteration(csgpu_search *s) {
  * would decide in between (how many parents, where the survivors go, the incumbent, whether to stop) decided by
  * single-workgroup kernels from state in device memory; the host reads the totals once per burst. */
 static int burst_applicable(const csgpu_search *s) {
-  return !s->burst_off && s->objective != CS_OBJ_ALL && s->parents_max <= SMALL_PARENTS &&
+  const int64_t most = s->burst_split && s->objective != CS_OBJ_ANY ? BURST_PARENTS_MAX : SMALL_PARENTS;
+  return !s->burst_off && s->objective != CS_OBJ_ALL && s->parents_max <= most &&
          s->parents_max * s->max_width <= s->max_children;
 }
 
@@ -1973,6 +1981,7 @@ static int enqueue_burst(csgpu_search *s, hipStream_t st) {
   while (cpb > 4 && bound / cpb < 2048) cpb >>= 1;
   /* ANY dives with few parents and must see the accept before it decides: one workgroup */
   const int split = s->burst_split && s->objective != CS_OBJ_ANY;
+  const unsigned burst_wgs = (unsigned)((s->parents_max + BURST_PPW - 1) / BURST_PPW); /* <= BURST_WGS_MAX: burst_applicable */
   /* Without expression-tree clauses a complete consistent child IS a solution, and evaluating the root (eval_wand over
    * every clause, eval.c:233-255) can only say "true": every clause is a binary relation or a two-literal disjunction
    * whose revision on valued operands fails exactly when it is violated, and each was revised after the last of its
@@ -1981,12 +1990,12 @@ static int enqueue_burst(csgpu_search *s, hipStream_t st) {
   const int *truth = s->burst_no_eval ? (const int *)NULL : (const int *)s->d_truth;
   for (int it = 0; it < BURST_ITERATIONS; it++) {
     if (split) {
-      hipLaunchKernelGGL(cs_burst_branch, dim3(BURST_WGS), dim3(1024), 0, st, s->pool, n, s->d_counters, s->d_burst,
+      hipLaunchKernelGGL(cs_burst_branch, dim3(burst_wgs), dim3(1024), 0, st, s->pool, n, s->d_counters, s->d_burst,
                          s->objective, (long long)s->max_width, (long long)s->cap, room_limit, s->holes, s->d_choice,
                          s->d_block_sum, s->d_block_skip, (const cs_val *)s->d_child_states,
                          (const int *)s->d_complete_list, truth, s->obj_var, s->d_solutions,
                          (long long)s->max_solutions, s->d_best_solution, s->d_best);
-      hipLaunchKernelGGL(cs_burst_emit, dim3(BURST_WGS), dim3(1024), 0, st, s->d_nodes, s->d_counters, s->d_burst,
+      hipLaunchKernelGGL(cs_burst_emit, dim3(burst_wgs), dim3(1024), 0, st, s->d_nodes, s->d_counters, s->d_burst,
                          s->objective, (const cs_choice *)s->d_choice, (const int *)s->d_block_sum,
                          (const int *)s->d_block_skip);
     } else

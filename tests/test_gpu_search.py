@@ -594,6 +594,7 @@ def test_split_bookkeeping_of_min_iterations_walks_the_same_tree(monkeypatch):
     from csolve_amd.solver import Search, solve_root
     model = solve_root(problems.schedule(8, seed=3))
     stats = {}
+    monkeypatch.setenv("CSGPU_SEARCH_PARENTS_MAX", "1024")  # what one workgroup can scan: the same batches in every mode
     for mode in ("split", "one", "evaluated"):
         monkeypatch.delenv("CSGPU_SEARCH_BURST_SPLIT", raising=False)
         monkeypatch.delenv("CSGPU_SEARCH_EVAL", raising=False)
@@ -608,6 +609,13 @@ def test_split_bookkeeping_of_min_iterations_walks_the_same_tree(monkeypatch):
         stats[mode] = st
     assert stats["split"] == stats["one"] == stats["evaluated"]
     assert stats["split"]["iterations"] > 10 and stats["split"]["nodes"] > 10000
+    # the default, 2,048 parents (thirty-two workgroups): the same optimum over fewer, fuller iterations
+    monkeypatch.delenv("CSGPU_SEARCH_PARENTS_MAX", raising=False)
+    monkeypatch.delenv("CSGPU_SEARCH_EVAL", raising=False)
+    s = Search(model, 1 << 21, 1 << 17)
+    s.put(model.root_state())
+    wide = s.run(1 << 30)
+    assert wide["done"] == 1 and wide["best"] == stats["split"]["best"] and wide["iterations"] <= stats["split"]["iterations"]
 
 
 def _prefix_state(model, steps, seed):

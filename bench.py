@@ -408,7 +408,8 @@ def search_workload(args, rank, world, local, dist):
         text = problems.schedule(args.search_schedule, 1)
         what = f"schedule-{args.search_schedule} MIN (examples/schedule.txt style)"
     r = run_sharded_search(args, rank, world, dist, text, args.steps, args.warmup, time_limit=args.time_limit,
-                           children=args.children, pool=args.pool, slice_iterations=args.slice,
+                           children=args.children or (1 << 21 if args.search_schedule else 0), pool=args.pool,
+                           slice_iterations=args.slice,
                            max_slices=args.search_slices)
     totals = r["totals"]
     if rank == 0:
@@ -464,7 +465,9 @@ def search_record(args, rank, world, dist):
                                         f"nodes explored per second by the whole job")
     sched = args.search_record_schedule
     if sched > 0:
-        rec(f"schedule{sched}_min", problems.schedule(sched, 1), steps=1, warmup=0)
+        # (a child buffer of 2^21: a MIN iteration takes as many parents as it can be sure to hold the children of --
+        # parents x widest interval -- and 8,192 parents per iteration, 1.68 s, is where schedule-12 is fastest; 2^19: 2.3 s)
+        rec(f"schedule{sched}_min", problems.schedule(sched, 1), steps=1, warmup=0, children=1 << 21)
         out[f"schedule{sched}_min"]["workload"] = (f"schedule-{sched} MIN (examples/schedule.txt style, BASELINE configs[4] shape): the "
                                                    f"incumbent bound travels between the ranks")
     return out

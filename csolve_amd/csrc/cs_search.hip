@@ -58,12 +58,13 @@ struct cs_choice {
 
 /* state of the device-driven iterations, in device memory between the kernels of a burst */
 enum { B_TOP = 0, B_BUDGET, B_LIMIT, B_LIMIT_MAX, B_ITER_BASE, B_ITERS, B_NODES, B_CUTS, B_PROPS, B_REVS, B_PEAK, B_ERROR,
-       B_SCATTER_BASE, B_IMPROVED, B_D_PARENTS, B_D_FIRST, B_D_ITER /* the iteration cs_burst_branch decided on */, B_COUNT };
+       B_SCATTER_BASE, B_IMPROVED, B_D_PARENTS, B_D_FIRST, B_D_ITER /* the iteration cs_burst_branch decided on */,
+       B_BACKLOG_DIV /* parents = pool / this, within [B_LIMIT, B_LIMIT_MAX] */, B_COUNT };
 #define BURST_ITERATIONS 16
 /* a MIN / MAX iteration's bookkeeping is spread over this many workgroups (one workgroup is bound by what ONE CU
  * reads, ~25 GB/s: 1,024 parent rows took it 24 us, 10,000 results 18 us) */
 #define BURST_PPW 64        /* parents per workgroup: sixteen lanes each, one pass of 1,024 threads */
-#define BURST_WGS_MAX 64    /* one wave adds up the workgroups' child counts: at most 4,096 parents per iteration */
+#define BURST_WGS_MAX 256   /* one wave adds up the workgroups' child counts, four each: at most 16,384 parents per iteration */
 #define BURST_PARENTS_MAX (BURST_PPW * BURST_WGS_MAX)
 #define BURST_CLASS_WGS 32
 
@@ -772,9 +773,9 @@ __device__ __forceinline__ cs_burst_head cs_burst_decide(const unsigned long lon
   h.error = 0;
   const long long top = (long long)burst[B_TOP];
   /* a few parents while the pool is small (dive for a solution / an incumbent first), more once there is a
-   * backlog of open states: 1/16 of the pool, within [B_LIMIT, B_LIMIT_MAX] (schedule-10: 0.7 s instead of 1.6 s
-   * with 64 throughout; small searches lose a few ms) */
-  long long limit = top / 16;
+   * backlog of open states: a share of the pool (B_BACKLOG_DIV), within [B_LIMIT, B_LIMIT_MAX] (schedule-10: 0.7 s
+   * instead of 1.6 s with 64 throughout; small searches lose a few ms) */
+  long long limit = top / (long long)burst[B_BACKLOG_DIV];
   limit = limit < (long long)burst[B_LIMIT] ? (long long)burst[B_LIMIT] : limit;
   limit = limit > (long long)burst[B_LIMIT_MAX] ? (long long)burst[B_LIMIT_MAX] : limit;
   long long parents = top < limit ? top : limit;
@@ -931,7 +932,7 @@ __global__ __launch_bounds__(1024) void cs_burst_emit(csgpu_node *__restrict__ n
                                                       unsigned long long *__restrict__ burst, int objective,
                                                       const cs_choice *__restrict__ choice,
                                                       const int *__restrict__ wg_sum, const int *__restrict__ wg_skip) {
-  const int wgs = (int)gridDim.x; /* <= BURST_WGS_MAX = the lanes of the wave that adds them up */
+  const int wgs = (int)gridDim.x; /* <= BURST_WGS_MAX */
   __shared__ cs_choice s_choice[BURST_PPW];
   __shared__ int s_off[BURST_PPW];
   const int g = (int)blockIdx.x;
@@ -946,8 +947,13 @@ __global__ __launch_bounds__(1024) void cs_burst_emit(csgpu_node *__restrict__ n
     if (p < parents) c = choice[p];
     s_choice[t] = c;
     /* the children before this workgroup's parents, then before this parent */
-    int before = t < g ? wg_sum[t] : 0;
-    int all = t < wgs ? wg_sum[t] : 0, all_skip = t < wgs ? wg_skip[t] : 0;
+    int before = 0, all = 0, all_skip = 0;
+    for (int h = t; h < wgs; h += 64) {
+      const int sum = wg_sum[h];
+      before += h < g ? sum : 0;
+      all += sum;
+      all_skip += wg_skip[h];
+    }
     int incl = c.count;
     for (int d = 1; d < 64; d <<= 1) {
       const int up = __shfl_up(incl, d);
@@ -1309,8 +1315,12 @@ extern "C" int csgpu_search_create(const csgpu_model *m, int64_t pool_capacity, 
     /* parents of a device-driven MIN / MAX iteration once the pool holds a backlog (tuning: CSGPU_SEARCH_PARENTS_MAX) */
     /* schedule-12 MIN: 9.7 s with 256, 7.3 s with 512, 6.3 s with 1,024 (round 3, single-workgroup bookkeeping); with the
      * bookkeeping over many workgroups 3.84 s with 1,024 and 3.37 s with 2,048 (10 % more nodes in 20 % fewer, fuller
-     * iterations; 4,096 changes nothing: a twentieth of the pool is rarely that many) */
-    int64_t want = 2048;
+     * iterations).  What holds an iteration down after that is the share of the pool it takes -- a sixteenth of it was
+     * rarely 2,048 states -- and the child buffer (parents x widest interval must fit): with a QUARTER of the pool per
+     * iteration schedule-12 takes 2.30 s at 2,048 parents, 1.80 s at 4,096 (2^20 children), 1.68 s at 8,192 (2^21;
+     * 1.53e9 nodes in 11,001 iterations of 150 us: the fixpoint kernel at its throughput) and 1.87 s at 16,384 -- from
+     * there on the nodes the breadth costs (2.1e9) outweigh the launches it saves */
+    int64_t want = 8192; /* see the next paragraph of this comment, and B_BACKLOG_DIV in run_burst */
     {
       const char *e = getenv("CSGPU_SEARCH_PARENTS_MAX");
       if (e != NULL && atoll(e) > 0) want = atoll(e);
@@ -2077,6 +2087,8 @@ static int run_burst(csgpu_search *s, int64_t budget, int64_t *done) {
   h[B_BUDGET] = (unsigned long long)(budget < BURST_ITERATIONS ? budget : BURST_ITERATIONS);
   h[B_LIMIT] = (unsigned long long)s->parents_limit;
   h[B_LIMIT_MAX] = (unsigned long long)s->parents_max;
+  h[B_BACKLOG_DIV] = 4ull; /* a quarter of the pool per iteration, within [B_LIMIT, B_LIMIT_MAX] (was a sixteenth: see csgpu_search_create) */
+  { const char *e = getenv("CSGPU_SEARCH_BACKLOG_DIV"); if (e != NULL && atoi(e) >= 1) h[B_BACKLOG_DIV] = (unsigned long long)atoi(e); } /* tuning */
   h[B_ITER_BASE] = (unsigned long long)s->st.iterations;
   h[B_PEAK] = (unsigned long long)s->peak;
   HIP_OK(hipMemcpyAsync(s->d_burst, h, sizeof(unsigned long long) * B_COUNT, hipMemcpyHostToDevice, s->burst_stream));

@@ -66,7 +66,7 @@ enum { B_TOP = 0, B_BUDGET, B_LIMIT, B_LIMIT_MAX, B_ITER_BASE, B_ITERS, B_NODES,
 #define BURST_PPW 64        /* parents per workgroup: sixteen lanes each, one pass of 1,024 threads */
 #define BURST_WGS_MAX 256   /* one wave adds up the workgroups' child counts, four each: at most 16,384 parents per iteration */
 #define BURST_PARENTS_MAX (BURST_PPW * BURST_WGS_MAX)
-#define BURST_CLASS_WGS 32
+#define BURST_CLASS_WGS 128 /* at most 1,024: a workgroup adds up the others' counts one per thread */
 
 struct csgpu_search {
   const csgpu_model *m;
@@ -1039,8 +1039,12 @@ __global__ __launch_bounds__(1024) void cs_burst_assign(const csgpu_result *__re
   const int g = (int)blockIdx.x;
   int beg, end;
   cs_burst_share((int)counters[C_TOTAL_CHILDREN], g, &beg, &end);
-  long long carry = 0; /* survivors | complete children << 32 before this workgroup's share */
-  for (int h = 0; h < g; h++) carry += (long long)wg_surv[h] | ((long long)wg_comp[h] << 32);
+  /* survivors | complete children << 32 of every workgroup, one per thread: the sum of the predecessors' and of all */
+  const int t = (int)threadIdx.x;
+  const long long mine = t < BURST_CLASS_WGS ? (long long)wg_surv[t] | ((long long)wg_comp[t] << 32) : 0ll;
+  long long carry, classes_all;
+  (void)cs_block_excl_scan(t < g ? mine : 0ll, s_part, &carry);
+  (void)cs_block_excl_scan(mine, s_part, &classes_all);
   const int first_surv = (int)(carry & 0xffffffffll);
   for (int base = beg; base < end; base += 1024) {
     const int i = base + (int)threadIdx.x;
@@ -1082,11 +1086,13 @@ __global__ __launch_bounds__(1024) void cs_burst_assign(const csgpu_result *__re
       }
     }
   }
-  if (g == 0 && threadIdx.x == 0) {
-    long long surv = 0, comp = 0, cuts = 0, props = 0, revs = 0;
-    for (int h = 0; h < BURST_CLASS_WGS; h++) {
-      surv += wg_surv[h]; comp += wg_comp[h]; cuts += wg_cuts[h]; props += wg_props[h]; revs += wg_revs[h];
-    }
+  if (g != 0) return; /* uniform */
+  long long cuts, props, revs;
+  (void)cs_block_excl_scan(t < BURST_CLASS_WGS ? (long long)wg_cuts[t] : 0ll, s_part, &cuts);
+  (void)cs_block_excl_scan(t < BURST_CLASS_WGS ? (long long)wg_props[t] : 0ll, s_part, &props);
+  (void)cs_block_excl_scan(t < BURST_CLASS_WGS ? (long long)wg_revs[t] : 0ll, s_part, &revs);
+  if (threadIdx.x == 0) {
+    const long long surv = classes_all & 0xffffffffll, comp = classes_all >> 32;
     counters[C_SURVIVORS] = (unsigned long long)surv;
     counters[C_COMPLETE] = (unsigned long long)comp;
     counters[C_CUTS] = (unsigned long long)cuts;

@@ -50,7 +50,7 @@ struct csgpu_model {
   int finalized;
   cs_dev_image *img; /* search image */
   /* device copies of the image */
-  int *d_adj_off, *d_adj, *d_clause, *d_tree_off, *d_tnode, *d_tkid, *d_tree_want, *d_lit;
+  int *d_adj_off, *d_adj, *d_clause, *d_tree_off, *d_tnode, *d_tkid, *d_tree_want, *d_lit, *d_clause_by_kind;
   cs_tables tab;
   size_t slice;      /* LDS bytes per node instance (16-byte aligned) */
   int has_tree_adj;  /* some adjacency entry is a tree clause */
@@ -256,7 +256,7 @@ static void free_device(csgpu_model *m) {
   if (m->srv_stream != NULL) (void)hipStreamDestroy(m->srv_stream);
   m->srv_stream = NULL;
   m->srv_off = 0;
-  (void)hipFree(m->d_adj_off); (void)hipFree(m->d_adj); (void)hipFree(m->d_clause);
+  (void)hipFree(m->d_adj_off); (void)hipFree(m->d_adj); (void)hipFree(m->d_clause); (void)hipFree(m->d_clause_by_kind);
   (void)hipFree(m->d_tree_off); (void)hipFree(m->d_tnode); (void)hipFree(m->d_tkid); (void)hipFree(m->d_tree_want);
   (void)hipFree(m->d_lit);
   m->d_tree_want = NULL;
@@ -290,7 +290,7 @@ static void free_device(csgpu_model *m) {
   if (m->h_values != NULL) (void)hipHostFree(m->h_values);
   m->h_values = m->d_values = NULL;
   m->values_cap = 0;
-  m->d_adj_off = m->d_adj = m->d_clause = m->d_tree_off = m->d_tnode = m->d_tkid = NULL;
+  m->d_adj_off = m->d_adj = m->d_clause = m->d_tree_off = m->d_tnode = m->d_tkid = m->d_clause_by_kind = NULL;
   m->d_one_in = m->d_one_out = NULL;
   m->d_one_node = NULL;
   m->d_one_res = NULL;
@@ -351,7 +351,7 @@ extern "C" int csgpu_model_device_info(const csgpu_model *m, int64_t info[8]) {
 /* ---- device image ------------------------------------------------------------------ */
 
 struct dev_tables_owner {
-  int *adj_off, *adj, *clause, *tree_off, *tnode, *tkid, *tree_want, *lit;
+  int *adj_off, *adj, *clause, *tree_off, *tnode, *tkid, *tree_want, *lit, *clause_by_kind;
 };
 
 static int upload(const void *src, size_t bytes, int **dst) {
@@ -366,6 +366,22 @@ static int upload_image(const cs_dev_image *g, dev_tables_owner *o, cs_tables *t
   if ((rc = upload(g->adj_off, ((size_t)g->n_vars + 1) * 4, &o->adj_off))) return rc;
   if ((rc = upload(g->adj, (size_t)(g->n_adj ? g->n_adj : 1) * 8, &o->adj))) return rc;
   if ((rc = upload(g->clause, (size_t)(g->n_clauses ? g->n_clauses : 1) * 16, &o->clause))) return rc;
+  {
+    /* the clause records once more, sorted by kind -- disjunctions, then < and =, then !=, trees, constants -- for the
+     * kernel that gives every lane its own clauses (kernel 6): a round revises ALL clauses whatever their order, and 64
+     * lanes of one kind run one path instead of all of them one after the other */
+    const int32_t nc = g->n_clauses;
+    int32_t *sorted = (int32_t *)malloc((size_t)(nc ? nc : 1) * 16);
+    if (sorted == NULL) return set_err(CSGPU_E_LIMIT, "out of memory");
+    static const int order[] = { CS_CL_OR2, CS_CL_LT, CS_CL_EQ, CS_CL_NE, CS_CL_TREE, CS_CL_SKIP };
+    int32_t k = 0;
+    for (size_t q = 0; q < sizeof order / sizeof order[0]; q++)
+      for (int32_t c = 0; c < nc; c++)
+        if (g->clause[4 * c] == order[q]) { memcpy(sorted + 4 * k, g->clause + 4 * c, 16); k++; }
+    rc = k == nc ? upload(sorted, (size_t)(nc ? nc : 1) * 16, &o->clause_by_kind) : set_err(CSGPU_E_STATE, "clause of unknown kind");
+    free(sorted);
+    if (rc) return rc;
+  }
   if ((rc = upload(g->tree_off, ((size_t)g->n_trees + 1) * 4, &o->tree_off))) return rc;
   if ((rc = upload(g->tnode, (size_t)(g->n_tnodes ? g->n_tnodes : 1) * 16, &o->tnode))) return rc;
   if ((rc = upload(g->tkid, (size_t)(g->n_tkids ? g->n_tkids : 1) * 4, &o->tkid))) return rc;
@@ -377,6 +393,7 @@ static int upload_image(const cs_dev_image *g, dev_tables_owner *o, cs_tables *t
   t->adj_off = o->adj_off;
   t->adj = (const int2 *)o->adj;
   t->clause = (const int4 *)o->clause;
+  t->clause_by_kind = (const int4 *)o->clause_by_kind;
   t->tree_off = o->tree_off;
   t->tnode = (const int4 *)o->tnode;
   t->tkid = o->tkid;
@@ -392,7 +409,7 @@ static int upload_image(const cs_dev_image *g, dev_tables_owner *o, cs_tables *t
 }
 
 static void free_tables(dev_tables_owner *o) {
-  (void)hipFree(o->adj_off); (void)hipFree(o->adj); (void)hipFree(o->clause);
+  (void)hipFree(o->adj_off); (void)hipFree(o->adj); (void)hipFree(o->clause); (void)hipFree(o->clause_by_kind);
   (void)hipFree(o->tree_off); (void)hipFree(o->tnode); (void)hipFree(o->tkid); (void)hipFree(o->tree_want);
   (void)hipFree(o->lit);
 }
@@ -788,7 +805,7 @@ extern "C" int csgpu_model_finalize(csgpu_model *m) {
     }
     free(vals); free(entailed);
   }
-  m->d_adj_off = own.adj_off; m->d_adj = own.adj; m->d_clause = own.clause;
+  m->d_adj_off = own.adj_off; m->d_adj = own.adj; m->d_clause = own.clause; m->d_clause_by_kind = own.clause_by_kind;
   m->d_tree_off = own.tree_off; m->d_tnode = own.tnode; m->d_tkid = own.tkid; m->d_tree_want = own.tree_want;
   m->d_lit = own.lit;
   if (rc != CSGPU_OK) return rc;

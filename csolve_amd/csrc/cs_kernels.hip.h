@@ -59,6 +59,7 @@ struct cs_tables {
   const int *adj_off;
   const int2 *adj;
   const int4 *clause;
+  const int4 *clause_by_kind; /* the same records sorted by kind (kernel 6: the 64 lanes of a slot then mostly run one path) */
   const int *tree_off;
   const int4 *tnode;
   const int *tkid;
@@ -660,7 +661,7 @@ __global__ __launch_bounds__(CS_BLOCK) void cs_propagate_clause_rounds(cs_tables
 #pragma unroll
   for (int q = 0; q < CPL; q++) {
     const int c = lane + q * CS_WAVE;
-    rec[q] = c < T.n_clauses ? T.clause[c] : make_int4(CS_CL_SKIP, 0, 0, 0);
+    rec[q] = c < T.n_clauses ? T.clause_by_kind[c] : make_int4(CS_CL_SKIP, 0, 0, 0);
     lit0[q] = rec[q].x == CS_CL_OR2 ? T.lit[rec[q].y] : make_int4(0, 0, 0, 0);
     lit1[q] = rec[q].x == CS_CL_OR2 ? T.lit[rec[q].y + 1] : make_int4(0, 0, 0, 0);
   }

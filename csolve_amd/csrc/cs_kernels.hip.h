@@ -773,6 +773,7 @@ __global__ __launch_bounds__(CS_BLOCK) void cs_propagate_clause_rounds(cs_tables
  */
 #define CS_CHUNK 16 /* nodes a wave takes at a time: their records sit in lanes 0..15 */
 __device__ __forceinline__ int cs_wave_sum(int x); /* below */
+__device__ __forceinline__ unsigned cs_wave_or(unsigned x); /* below */
 
 /* ADJ_LDS = false: the adjacency stays in device memory (it is a few tens of KB that every workgroup reads: L2-resident)
  * and LDS holds the per-wave slices only -- for models whose lists would leave room for a handful of waves (a 25x25
@@ -921,6 +922,9 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_lds(cs
             const int beg = __builtin_amdgcn_readfirstlane(range.x), end = __builtin_amdgcn_readfirstlane(range.y);
             revisions += end - beg;
             const int is_value = ulo == uhi;
+            /* u open: which of the 32 values from each bound inwards does a valued neighbour forbid?  (bit p of flo:
+             * ulo + p, of fhi: uhi - p) */
+            unsigned flo = 0u, fhi = 0u;
             /* U strides at a time: all entry reads, then all domain reads, then the compares */
             for (int i0 = beg + lane; i0 < end; i0 += U * CS_WAVE) {
               unsigned e[U];
@@ -941,10 +945,40 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_lds(cs
                   const int f = ulo - d;
                   if (dw[k].lo == f) CS_RAISE(wv, f + 1);
                   else if (dw[k].hi == f) CS_LOWER(wv, f - 1);
-                } else if (dw[k].lo == dw[k].hi) { /* u is open: a valued neighbour on one of its bounds */
+                } else if (dw[k].lo == dw[k].hi) { /* u is open: a valued neighbour near one of its bounds */
                   const int f = dw[k].lo + d;
-                  if (f == ulo) CS_RAISE(u, f + 1);
-                  else if (f == uhi) CS_LOWER(u, f - 1);
+                  const unsigned pl = (unsigned)(f - ulo), ph = (unsigned)(uhi - f);
+                  if (pl < 32u) flo |= 1u << pl;
+                  if (ph < 32u) fhi |= 1u << ph;
+                }
+              }
+            }
+            if (!is_value) {
+              /* The whole list is seen: the bound moves past EVERY forbidden value in one step -- as many reference
+               * narrowings as values passed (each is one unit shave of propagate_eq_false_lr, propagate.c:106-120) --
+               * instead of one value per round with a scan of this list each.  The new bound is free of valued
+               * neighbours, so u comes back only when it has become a value (it then pushes) or 32 values were not enough. */
+              flo = cs_wave_or(flo);
+              fhi = cs_wave_or(fhi);
+              const int up = flo == 0xffffffffu ? 32 : __builtin_ctz(~flo), down = fhi == 0xffffffffu ? 32 : __builtin_ctz(~fhi);
+              if (lane == 0) {
+                if (up > 0) {
+                  const int lo_ = ulo + up, old = atomicMax(&dom[u].lo, lo_);
+                  if (old < lo_) {
+                    atomicAdd(pcount, (unsigned)(lo_ - old));
+                    const int hi_now = dom[u].hi;
+                    if (lo_ > hi_now) fail = 1;
+                    else if (lo_ == hi_now || up == 32) atomicOr(&nxt[u >> 5], 1u << (u & 31));
+                  }
+                }
+                if (down > 0 && !fail) {
+                  const int hi_ = uhi - down, old = atomicMin(&dom[u].hi, hi_);
+                  if (old > hi_) {
+                    atomicAdd(pcount, (unsigned)(old - hi_));
+                    const int lo_now = dom[u].lo;
+                    if (hi_ < lo_now) fail = 1;
+                    else if (hi_ == lo_now || down == 32) atomicOr(&nxt[u >> 5], 1u << (u & 31));
+                  }
                 }
               }
             }
@@ -1334,6 +1368,16 @@ __device__ __forceinline__ int cs_wave_sum(int x) {
   x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, true); /* row_bcast:15 into rows 1 and 3 */
   x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, true); /* row_bcast:31 into rows 2 and 3 */
   return __builtin_amdgcn_readlane(x, 63);
+}
+
+__device__ __forceinline__ unsigned cs_wave_or(unsigned x) { /* the OR over the 64 lanes, the same in every lane */
+  x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);
+  x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);
+  x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);
+  x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);
+  x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, true);
+  x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, true);
+  return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
 }
 
 /* FAST: n_vars == 64 * R and both set buffers are there -- every load and store of the node loop is

@@ -581,10 +581,12 @@ extern "C" int csgpu_model_eval_clauses_host(csgpu_model *m, csgpu_val *vals) {
 /* instantiation of the LDS-resident kernel for an entry width and a prefetch depth
  * R = ceil(n_vars / 64) rounded up to a power of two (at most 16: larger states load their tail in place) */
 static const void *ne_lds_kernel(int width, int n_vars, int adj_global) {
-  int r = 1;
-  while (r < 16 && r * CS_WAVE < n_vars) r <<= 1;
-  /* 513 to 640 variables (a 25x25 sudoku): ten strides, not sixteen with six of them empty */
-  if (r == 16 && n_vars <= 10 * CS_WAVE && !adj_global)
+  /* the largest instantiated depth that is at most ceil(n_vars / 64): all its strides but the last are full (the kernel
+   * relies on that), a longer state loads its tail in place */
+  const int strides = (n_vars + CS_WAVE - 1) / CS_WAVE;
+  int r = strides >= 16 ? 16 : (strides >= 8 ? 8 : (strides >= 4 ? 4 : (strides >= 2 ? 2 : 1)));
+  /* 577 to 1023 variables (a 25x25 sudoku has 625): ten strides in registers */
+  if (strides >= 10 && strides < 16 && !adj_global)
     return width == 2 ? (const void *)cs_propagate_ne_lds<unsigned short, 10, 1, true>
                       : (const void *)cs_propagate_ne_lds<unsigned int, 10, 1, true>;
 #define CS_PICK_U(E, RR) return adj_global ? (const void *)cs_propagate_ne_lds<E, RR, 1, false> : (const void *)cs_propagate_ne_lds<E, RR, 1, true>;

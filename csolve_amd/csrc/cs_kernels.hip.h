@@ -779,6 +779,8 @@ __device__ __forceinline__ unsigned cs_wave_or(unsigned x); /* below */
  * and LDS holds the per-wave slices only -- for models whose lists would leave room for a handful of waves (a 25x25
  * sudoku: 90 KB of lists, 5 KB per node), where latency, not LDS bandwidth, is what needs hiding.
  * csz: nodes a wave takes at a time (1..16; small for small batches, so that every wave gets a share). */
+/* R strides of 64 variables travel through registers; the host picks R with (R - 1) * 64 <= n, so that only the LAST of
+ * them asks "v < n" */
 template <typename E, int R, int U, bool ADJ_LDS = true>
 __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_lds(cs_tables T, const E *__restrict__ adj_packed, int n_adj,
                                                             int obits, int dmin,
@@ -830,7 +832,7 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_lds(cs
 #pragma unroll
       for (int r = 0; r < R; r++) {
         const int v = lane + r * CS_WAVE;
-        pre[r] = v < n ? src[v] : cs_value(0);
+        pre[r] = r < R - 1 || v < n ? src[v] : cs_value(0);
       }
     }
     for (int j = 0; j < cnt; j++) {
@@ -839,7 +841,7 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_lds(cs
 #pragma unroll
       for (int r = 0; r < R; r++) {
         const int v = lane + r * CS_WAVE;
-        if (v < n) dom[v] = pre[r];
+        if (r < R - 1 || v < n) dom[v] = pre[r];
       }
       for (int v = lane + R * CS_WAVE; v < n; v += CS_WAVE) /* n > 64*R: the tail is loaded in place */
         dom[v] = states_in[(size_t)__builtin_amdgcn_readlane(rec.parent, j) * n + v];
@@ -848,7 +850,7 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_lds(cs
 #pragma unroll
         for (int r = 0; r < R; r++) {
           const int v = lane + r * CS_WAVE;
-          pre[r] = v < n ? src[v] : cs_value(0);
+          pre[r] = r < R - 1 || v < n ? src[v] : cs_value(0);
         }
       }
       for (int w = lane; w < nw; w += CS_WAVE) { mask_a[w] = 0u; mask_b[w] = 0u; }
@@ -1007,12 +1009,12 @@ __global__ __launch_bounds__(1024, (R <= 2 ? 8 : 4)) void cs_propagate_ne_lds(cs
 #pragma unroll
         for (int r = 0; r < R; r++) {
           const int v = lane + r * CS_WAVE;
-          dd[r] = v < n ? dom[v] : cs_value(0);
+          dd[r] = r < R - 1 || v < n ? dom[v] : cs_value(0);
         }
 #pragma unroll
         for (int r = 0; r < R; r++) {
           const int v = lane + r * CS_WAVE;
-          if (v < n) dst[v] = dd[r];
+          if (r < R - 1 || v < n) dst[v] = dd[r];
           open_l += dd[r].lo != dd[r].hi ? 1 : 0;
         }
         for (int v = lane + R * CS_WAVE; v < n; v += CS_WAVE) {

@@ -484,9 +484,10 @@ def main():
                     "general kernel) instead of queens (BASELINE configs[4] shape)")
     ap.add_argument("--sudoku", type=int, default=0, help="box size N of an N^2 x N^2 sudoku-shaped != network instead of "
                     "queens (5 = BASELINE configs[2], 25x25)")
-    ap.add_argument("--instances", type=int, default=1 << 20, help="node instances per GPU (2^20 queens-64 instances are 1.1 GB per "
-                    "launch: four times the 256 MB Infinity Cache, so a repeated launch cannot be served from it; a launch "
-                    "of 2^18 takes 66 us instead of the 57 us a quarter of the large one takes: ramp and tail of a launch)")
+    ap.add_argument("--instances", type=int, default=1 << 21, help="node instances per GPU (2^21 queens-64 instances are 2.2 GB per "
+                    "launch: eight times the 256 MB Infinity Cache, so a repeated launch cannot be served from it; a launch "
+                    "of 2^18 takes 66 us, a quarter of one of 2^20 53 us, an eighth of one of 2^21 51 us: ramp and tail of a "
+                    "launch -- 0.607 / 0.639 / 0.644 of the roofline at 2^20 / 2^21 / 2^22)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch the timed steps one by one instead of as one hipGraph")

@@ -920,12 +920,12 @@ def sudoku25_record(args):
     a.queens, a.sudoku, a.schedule, a.layout = 64, 5, 0, "intervals"
     a.cpu_seconds = min(args.cpu_seconds, 4.0)
     text = problems.sudoku(5, 0.4, 1)  # 40 % of a seeded valid grid revealed
-    legs = run_propagation_legs(a, text, 1 << 18, seed=555, headline_only=True, steps=min(args.steps, 30))
+    legs = run_propagation_legs(a, text, 1 << 19, seed=555, headline_only=True, steps=min(args.steps, 30))  # 5.2 GB per launch (2^18: 0.47, 2^19: 0.52, 2^20: 0.53 of the roofline)
     leg = legs["legs"]["state_only"]
     rec = roofline_record(leg, "sudoku-25x25", legs["B"])
     ok = leg["results"][:, 0] >= 0
     t = leg["kernel_ms"] * 1e-3
-    out = {"workload": "sudoku-25x25 (40 % givens) propagation-only fixpoint, 262144 seeded random-walk node instances resident in HBM",
+    out = {"workload": "sudoku-25x25 (40 % givens) propagation-only fixpoint, 524288 seeded random-walk node instances resident in HBM",
            "entry": leg["entry"], "forbidden_sets_precomputed": False, "steps": leg["steps"],
            "nodes_per_s": legs["B"] / t, "value": int(leg["results"][ok, 1].sum()) / t, "unit": "propagations/s",
            "roofline": rec}

@@ -367,13 +367,13 @@ static int upload_image(const cs_dev_image *g, dev_tables_owner *o, cs_tables *t
   if ((rc = upload(g->adj, (size_t)(g->n_adj ? g->n_adj : 1) * 8, &o->adj))) return rc;
   if ((rc = upload(g->clause, (size_t)(g->n_clauses ? g->n_clauses : 1) * 16, &o->clause))) return rc;
   {
-    /* the clause records once more, sorted by kind -- disjunctions, then < and =, then !=, trees, constants -- for the
+    /* the clause records once more, sorted by kind -- =, <, !=, then disjunctions, trees, constants -- for the
      * kernel that gives every lane its own clauses (kernel 6): a round revises ALL clauses whatever their order, and 64
      * lanes of one kind run one path instead of all of them one after the other */
     const int32_t nc = g->n_clauses;
     int32_t *sorted = (int32_t *)malloc((size_t)(nc ? nc : 1) * 16);
     if (sorted == NULL) return set_err(CSGPU_E_LIMIT, "out of memory");
-    static const int order[] = { CS_CL_OR2, CS_CL_LT, CS_CL_EQ, CS_CL_NE, CS_CL_TREE, CS_CL_SKIP };
+    static const int order[] = { CS_CL_EQ, CS_CL_LT, CS_CL_NE, CS_CL_OR2, CS_CL_TREE, CS_CL_SKIP };
     int32_t k = 0;
     for (size_t q = 0; q < sizeof order / sizeof order[0]; q++)
       for (int32_t c = 0; c < nc; c++)

@@ -335,7 +335,9 @@ def run_sharded_search(args, rank, world, dist, text, steps, warmup, time_limit=
     def once():
         eng.reset()
         sh = ShardedSearch(eng, model.objective, n, rank, world, dist, engine_device="cuda", comm_device=comm,
-                           slice_iterations=slice_iterations or (64 if model.objective == 1 else 256),  # 1 = ALL; a dry rank calls the exchange earlier
+                           # a dry rank calls the exchange earlier.  (MIN / MAX used 256 while an iteration was 45 us and 10,000
+                           # nodes; at 137 us and 139,000 nodes 64 iterations are 9 ms: two ranks on one GPU 2.29 -> 1.97 s)
+                           slice_iterations=slice_iterations or 64,
                            seed_states_per_rank=256, low_water=4096, poll_iterations=args.poll,
                            time_limit=time_limit if time_limit else None)
         local_stats, totals = sh.run(model.root_state(), max_slices if max_slices > 0 else 1 << 40)
@@ -515,8 +517,8 @@ def main():
     ap.add_argument("--pool", type=int, default=0, help="search workload: rows of the state pool (default: 8 x --children)")
     ap.add_argument("--children", type=int, default=0, help="search workload: children per iteration at most "
                     "(default: 2^21 for models of at most 32 variables, else 2^19)")
-    ap.add_argument("--slice", type=int, default=0, help="search iterations between regular rank exchanges (default: 64 for ALL, "
-                    "256 for ANY / MIN / MAX; a rank that runs dry calls the exchange earlier through the status page)")
+    ap.add_argument("--slice", type=int, default=0, help="search iterations between regular rank exchanges (default: 64; "
+                    "a rank that runs dry calls the exchange earlier through the status page)")
     ap.add_argument("--search-slices", type=int, default=0,
                     help="stop a search after this many slices (0 = run to the end): ALL on trees too large to finish")
     ap.add_argument("--no-search", action="store_true", help="skip the `search` sub-record (the sharded search next to the "
